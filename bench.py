@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- processed edges/sec of the R-GCN encoder forward+backward (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one minibatch graph already resident in HBM:
+device-side graph preparation of the fed [E,3] triples + 2-layer encoder forward (train mode, generated
+self-loop dropout) + backward for every encoder weight (rgcn_step_device).  value = E_g * steps / s.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  "roofline":     the dominant kernel against its gfx950 roofline (live HIP-event durations),
+  "kernels":      the same accounting for every kernel of the step,
+  "cpu_baseline": the CPU oracle (TF-dataflow-shaped numpy/scipy port of the reference) timed on
+                  this box's host cores on the same minibatch.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+PEAK_F32_MFMA_TFS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+WORKLOADS = {
+    # name: (graph fixture | None, V, R, d, L, kind, nb, E_g)   -- BASELINE.json configs[1] is the headline
+    "fb237_block": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 15000),
+    "fb237_block_fullgraph": ("fb237_valid_test", 14541, 237, 500, 2, "block", 100, 38001),
+    "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="fb237_block", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-steps", type=int, default=4, help="timed CPU-oracle steps (0 disables)")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+
+    dist = None
+    if world > 1:
+        # control plane only (rendezvous of the RCCL id, barriers); the data path is our own RCCL
+        # communicator on the engine's stream.  torch is imported BEFORE librgcn.so so that one HIP
+        # runtime image serves the whole process.
+        import torch  # noqa: F401
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from relationprediction_amd import _native
+    from relationprediction_amd.sharding import lpt_partition
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers  # seeded workload construction shared with the parity tests
+
+    graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[args.workload]
+    triples = helpers.load_graph(graph_name)
+    assert triples.shape[0] == E_g
+    from relationprediction_amd.common.shared_functions import init_encoder_params
+    params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
+    dcodes = (np.random.RandomState(2).randn(V, d) * 1e-3).astype(np.float32)
+
+    eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
+                         device=local_rank, rank=rank, world=world)
+    eng.set_params(params)
+    if world > 1:
+        owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
+        eng.set_relation_owner(owner)
+        ids = [_native.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0])
+    tri_dev = eng.to_device(triples)
+    dc_dev = eng.to_device(dcodes)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def run(n, seed0):
+        for i in range(n):
+            eng.step_device(tri_dev, E_g, dc_dev, train=True, seed=seed0 + i)
+
+    run(args.warmup, 1000)
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    run(args.steps, 2000)
+    gpu_ms = eng.timer_stop()
+    eng.sync()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = E_g * args.steps / wall
+
+    # ---- per-kernel accounting: same steps again with HIP events around every launch
+    kernels, roofline = [], None
+    if not args.no_kernel_profile:
+        eng.profile_reset()
+        eng.profile_enable(True)
+        run(args.steps, 2000)
+        prof = eng.profile()
+        eng.profile_enable(False)
+        for p in prof:
+            if p["calls"] == 0:
+                continue
+            avg_ms = p["total_ms"] / p["calls"]
+            by, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
+            t_hbm = by / (PEAK_HBM_GBS * 1e9)
+            t_mfma = fl / (PEAK_F32_MFMA_TFS * 1e12)
+            bound = "mfma" if t_mfma > t_hbm else "hbm"
+            sec = max(avg_ms, 1e-9) * 1e-3
+            if bound == "mfma":
+                ach, peak, unit = fl / sec / 1e12, PEAK_F32_MFMA_TFS, "TFLOP/s"
+            else:
+                ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+            kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / args.steps,
+                            "avg_us": round(avg_ms * 1e3, 2), "ms_per_step": round(p["total_ms"] / args.steps, 4),
+                            "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                            "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        if kernels:
+            k = kernels[0]
+            roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                        "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_us": k["avg_us"],
+                        "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
+
+    # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        import oracle  # test infrastructure; used here ONLY as the timed CPU baseline
+        masks = [(np.random.RandomState(3 + l).rand(V, d) < 0.8).astype(np.uint8) for l in range(L)]
+        oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)  # warm-up
+        ts = []
+        for _ in range(args.cpu_steps):
+            c0 = time.perf_counter()
+            oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)
+            ts.append(time.perf_counter() - c0)
+        med = float(np.median(ts))
+        cpu = {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+               "ms_per_step": round(med * 1e3, 1),
+               "sample": "%d steps of the same %s minibatch (E_g=%d) through oracle.encoder_step "
+                         "(numpy/scipy fp32, TF-dataflow-shaped), median" % (args.cpu_steps, args.workload, E_g)}
+
+    if rank == 0:
+        out = {
+            "metric": "processed edges/sec (R-GCN forward+backward), FB15k-237 gcn_block",
+            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "real FB15k-237 valid+test graph structure (15,000-edge minibatch per SURVEY 8d), "
+                    "reference-distribution random-init weights, synthetic upstream gradient",
+            "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
+                       "kind": kind, "num_blocks": nb, "graph_edges": E_g,
+                       "step": "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
+                       "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
+            "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
+            "message_edges_per_s": round(2 * L * value, 1),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    tri_dev.free()
+    dc_dev.free()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

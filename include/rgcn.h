@@ -1,0 +1,224 @@
+/*
+ * rgcn.h -- C ABI of librgcn.so: the MI355X-native R-GCN encoder hot path
+ * (forward + backward of MichSchli/RelationPrediction's `gcn_basis` encoder
+ * chain: AffineTransform -> L x {ConcatGcn | BasisGcn}).
+ *
+ * This is the drop-in boundary.  In the reference the
+ * Python plugin chain (code/model.py, code/encoders, code/common/model_builder.py)
+ * builds a TF-1.4 graph and crosses into native code at `session.run`
+ * (code/optimization/optimize.py:81-88 for training, code/model.py:56,69,81 for
+ * scoring).  Here the same plugin chain (package `relationprediction_amd`)
+ * crosses into this library through ctypes.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: `extern "C"`, no C++/torch types, no exceptions cross the boundary;
+ *   - every call returns an rgcn_status (0 = ok); rgcn_last_error() has the text;
+ *   - host pointers are BORROWED for the duration of the call only;
+ *   - device memory is owned by the context; `*_device` variants take device
+ *     pointers (HIP, same device) that the caller owns and keeps alive until
+ *     the next rgcn_sync();
+ *   - one context per (process, GPU); a context is not thread-safe; calls are
+ *     stream-ordered on the context's own HIP stream and asynchronous unless
+ *     they return host data;
+ *   - all floating point is float32, all indices int32 (reference:
+ *     code/extras/graph_representations.py:174, code/common/shared_functions.py:17).
+ */
+#ifndef RGCN_H_
+#define RGCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGCN_ABI_VERSION 1
+
+typedef struct rgcn_ctx rgcn_ctx;
+typedef int32_t rgcn_status;
+
+enum {
+  RGCN_OK = 0,
+  RGCN_ERR_INVALID = 1,     /* bad argument / out-of-range index / wrong size */
+  RGCN_ERR_HIP = 2,         /* a HIP runtime call failed */
+  RGCN_ERR_RCCL = 3,        /* an RCCL call failed / librccl not loadable */
+  RGCN_ERR_STATE = 4,       /* call order violated (e.g. backward before forward) */
+  RGCN_ERR_UNSUPPORTED = 5, /* configuration outside what the kernels implement */
+  RGCN_ERR_NOMEM = 6
+};
+
+/* Encoder.Concatenation=Yes -> ConcatGcn (block-diagonal), else BasisGcn:
+ * code/common/model_builder.py:291-294. */
+enum { RGCN_KIND_BLOCK = 0, RGCN_KIND_BASIS = 1 };
+
+/* Neighbour normalisation of the incidence matrices, normalization=('global', ...)
+ * (code/extras/graph_representations.py:82-93,122-133).  INTENDED = 1/deg(row of this edge);
+ * TF_AS_EXECUTED = SURVEY.md section 9 H1 (tf.sparse_softmax on non-canonical indices returns the
+ * values in sorted-row order); NONE = the 'none' branch (:70-81). */
+enum { RGCN_NORM_INTENDED = 0, RGCN_NORM_TF_AS_EXECUTED = 1, RGCN_NORM_NONE = 2 };
+
+/* Buffers readable through rgcn_read_buffer (tests / the sharding exchange). */
+enum {
+  RGCN_BUF_EXCHANGE = 0,   /* [V,d] buffer a multi-GPU run all-reduces (partial pre-activation / partial dH) */
+  RGCN_BUF_SELF = 1,       /* [V,d] self-loop product H.W_self of the last layer run */
+  RGCN_BUF_DSELF_EXCHANGE = 2, /* [d,d] partial dW_self a multi-GPU run all-reduces */
+  RGCN_BUF_INDEG = 3,      /* int32 [V] in-degree inside the fed graph  */
+  RGCN_BUF_OUTDEG = 4,     /* int32 [V] out-degree inside the fed graph */
+  RGCN_BUF_ROWPTR = 5      /* int32 [V+1] incidence CSR offsets (owned relations only) */
+};
+
+/*
+ * Replaces the settings the reference components parse in their constructors:
+ * Model.__init__ (code/model.py:17-25: EntityCount, RelationCount), ConcatGcn/BasisGcn.parse_settings
+ * (gcn_basis_concat.py:10-15, gcn_basis.py:10-13: DropoutKeepProbability, NumberOfBasisFunctions),
+ * build_encoder (model_builder.py:121-184: InternalEncoderDimension, NumberOfLayers).
+ */
+typedef struct rgcn_config {
+  int32_t abi_version;    /* must be RGCN_ABI_VERSION */
+  int32_t device;         /* HIP device ordinal */
+  int32_t num_entities;   /* V = EntityCount */
+  int32_t num_relations;  /* R = RelationCount */
+  int32_t dim;            /* d = InternalEncoderDimension (= CodeDimension, UseOutputTransform=No) */
+  int32_t num_layers;     /* L = NumberOfLayers */
+  int32_t kind;           /* RGCN_KIND_* */
+  int32_t num_bases;      /* NumberOfBasisFunctions: block count nb (BLOCK, d % nb == 0) or B (BASIS) */
+  float   keep_prob;      /* DropoutKeepProbability (self-loop dropout, train mode only) */
+  int32_t norm_mode;      /* RGCN_NORM_* */
+  int64_t max_edges;      /* capacity: largest E ever passed to rgcn_set_graph* */
+  int32_t rank;           /* relation-sharding rank in [0, world) */
+  int32_t world;          /* number of relation shards (1 = single GPU) */
+  int32_t reserved;       /* must be 0 */
+} rgcn_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+int32_t rgcn_abi_version(void);
+
+/* Replaces tf.Session() + Model.initialize_train() variable allocation
+ * (code/train.py:258,278; code/model.py:93-94).  Weights start as zeros: the host plugin chain
+ * draws the reference's numpy initialisers (shared_functions.py:16-29) and pushes them. */
+rgcn_status rgcn_create(const rgcn_config* cfg, rgcn_ctx** out);
+rgcn_status rgcn_destroy(rgcn_ctx* ctx);
+
+/* Text of the last error on this context (ctx == NULL: last error of a failed rgcn_create). */
+const char* rgcn_last_error(const rgcn_ctx* ctx);
+
+/* Wait for everything queued on the context's stream; also surfaces asynchronous device-side
+ * validation failures (out-of-range vertex / relation ids in a device-resident graph). */
+rgcn_status rgcn_sync(rgcn_ctx* ctx);
+
+/* ---- parameters (the encoder part of Model.get_weights(), code/model.py:96-97) ----------------
+ * Index order = reference order, innermost component first:
+ *   W_emb [V,d], b_emb [d]                                  (affine_transform.py:30-31)
+ *   per layer l=1..L:  BLOCK: W_f [R,nb,sd,sd], W_b [R,nb,sd,sd], W_self [d,d], b [d]
+ *                                                           (gcn_basis_concat.py:30-33)
+ *                      BASIS: W_f [d,B,d], W_b [d,B,d], C_f [R,B], C_b [R,B], W_self [d,d], b [d]
+ *                                                           (gcn_basis.py:33-37)
+ * Host layouts are the reference's (row-major, shapes above); the device layout is private.
+ * `b` is created but never used by the reference layers: it is stored, never read,
+ * and its gradient is all zeros.  W_relation is not an encoder-path weight and stays on the host. */
+int32_t     rgcn_param_count(const rgcn_ctx* ctx);
+rgcn_status rgcn_param_info(const rgcn_ctx* ctx, int32_t index, char* name, int32_t name_cap,
+                            int64_t shape[4], int32_t* ndim);
+/* replaces tf.Variable(initializer) / Saver.restore: shared_functions.py:16-22, model.py:38 */
+rgcn_status rgcn_set_param(rgcn_ctx* ctx, int32_t index, const float* host, int64_t count);
+/* replaces Saver.save / session.run(variable): model.py:30-37 */
+rgcn_status rgcn_get_param(rgcn_ctx* ctx, int32_t index, float* host, int64_t count);
+/* replaces the tensors tf.gradients(loss, weights) returns: optimization/abstract.py:117-118 */
+rgcn_status rgcn_get_grad(rgcn_ctx* ctx, int32_t index, float* host, int64_t count);
+
+/* ---- graph (the `graph_edges` placeholder, graph_representations.py:173-177) -------------------
+ * triples = int32 [E,3] rows (subject, relation, object) exactly as fed to the placeholder
+ * (MessageGraph.process, :21-27).  The call builds, on the device, everything the reference derives
+ * inside session.run: degrees, the 'global' normalisation values (:82-93,122-133), the
+ * relation-sorted message list and the incidence CSR.  Edge dropout (GraphSplitSize, train.py:235-238)
+ * is applied by the caller before the call: degrees are counted over the edges actually fed.
+ * 0 <= E <= max_edges.  The host variant validates ids and returns RGCN_ERR_INVALID on a bad one. */
+rgcn_status rgcn_set_graph(rgcn_ctx* ctx, const int32_t* triples_host, int64_t num_edges);
+rgcn_status rgcn_set_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges);
+
+/* ---- forward: get_all_codes(mode) (message_gcn.py:44-79, affine_transform.py:63-83) ------------
+ * train != 0 applies self-loop dropout (message_gcn.py:60-64).  The Bernoulli(keep_prob) draw is
+ *   - dropout_masks_host != NULL: the caller's uint8 [L,V,d] 0/1 masks (parity testing), else
+ *   - a counter-based generator keyed by (dropout_seed, layer, element) -- nothing is stored;
+ *     rgcn_get_dropout_mask() re-materialises what the last forward used.
+ * The result H_L [V,d] is the subject AND object code matrix (relation_embedding.py:23-25). */
+rgcn_status rgcn_forward(rgcn_ctx* ctx, int32_t train, uint64_t dropout_seed,
+                         const uint8_t* dropout_masks_host);
+rgcn_status rgcn_get_codes(rgcn_ctx* ctx, float* host, int64_t count);              /* H_L  */
+rgcn_status rgcn_get_activation(rgcn_ctx* ctx, int32_t layer, float* host, int64_t count); /* H_0..H_L */
+rgcn_status rgcn_get_dropout_mask(rgcn_ctx* ctx, int32_t layer /*1..L*/, uint8_t* host, int64_t count);
+const float* rgcn_codes_device(rgcn_ctx* ctx);                                      /* device H_L */
+
+/* ---- backward: tf.gradients(loss, weights) restricted to the encoder (abstract.py:117-118) -----
+ * dcodes = dL/dH_L [V,d] (the decoder's gradient w.r.t. subject+object codes, already summed).
+ * Needs a preceding rgcn_forward on the same graph.  Gradients are then readable by rgcn_get_grad. */
+rgcn_status rgcn_backward(rgcn_ctx* ctx, const float* dcodes_host, int64_t count);
+rgcn_status rgcn_backward_device(rgcn_ctx* ctx, const float* dcodes_dev);
+
+/* One whole 'step' of the BASELINE metric, fully asynchronous: graph prep + forward(train) +
+ * backward from device-resident inputs.  Replaces one session.run of the encoder part of
+ * TensorflowOptimizer.update_from_batch (optimize.py:81-88). */
+rgcn_status rgcn_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges,
+                             int32_t train, uint64_t dropout_seed, const float* dcodes_dev);
+
+/* ---- relation sharding across GPUs (new: the reference is single-device) ------------
+ * owner[r] in [0, world) assigns relation r's edges and W_f[r]/W_b[r] (BLOCK) or C_f[r]/C_b[r]
+ * (BASIS) to one rank.  Degrees stay global.  Must be identical on all ranks. */
+rgcn_status rgcn_set_relation_owner(rgcn_ctx* ctx, const int32_t* owner, int32_t count);
+/* RCCL bootstrap: rank 0 makes the id, the launcher broadcasts the 128 bytes, every rank inits.
+ * librccl.so.1 is dlopen'ed on first use; a world==1 context never touches it. */
+rgcn_status rgcn_comm_unique_id(uint8_t id[128]);
+rgcn_status rgcn_comm_init(rgcn_ctx* ctx, const uint8_t id[128]);
+/* sum-all-reduce of `count` floats at a device pointer on the context's stream (used by bench.py
+ * for its barrier / max-over-ranks reduction so that no second RCCL client is needed). */
+rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* ctx, float* dev, int64_t count);
+
+/* Phase API: the same forward/backward cut at the points where a sharded run exchanges data.
+ * rgcn_forward == begin; for l: partial(l) [all-reduce EXCHANGE] finish(l).
+ * rgcn_backward == begin; for l=L..1: partial(l) [all-reduce EXCHANGE, DSELF_EXCHANGE] finish(l); end.
+ * With world > 1 and no communicator the caller performs the exchange itself through
+ * rgcn_read_buffer / rgcn_write_buffer (single-GPU test double for the collective). */
+rgcn_status rgcn_forward_begin(rgcn_ctx* ctx, int32_t train, uint64_t dropout_seed,
+                               const uint8_t* dropout_masks_host);
+rgcn_status rgcn_forward_layer_partial(rgcn_ctx* ctx, int32_t layer);
+rgcn_status rgcn_forward_layer_finish(rgcn_ctx* ctx, int32_t layer);
+rgcn_status rgcn_backward_begin(rgcn_ctx* ctx, const float* dcodes_dev);
+rgcn_status rgcn_backward_layer_partial(rgcn_ctx* ctx, int32_t layer);
+rgcn_status rgcn_backward_layer_finish(rgcn_ctx* ctx, int32_t layer);
+rgcn_status rgcn_backward_end(rgcn_ctx* ctx);
+rgcn_status rgcn_read_buffer(rgcn_ctx* ctx, int32_t which, void* host, int64_t bytes);
+rgcn_status rgcn_write_buffer(rgcn_ctx* ctx, int32_t which, const void* host, int64_t bytes);
+
+/* ---- device memory + timing helpers (so callers need no other GPU runtime) -------------------- */
+rgcn_status rgcn_device_alloc(rgcn_ctx* ctx, int64_t bytes, void** dev);
+rgcn_status rgcn_device_free(rgcn_ctx* ctx, void* dev);
+rgcn_status rgcn_copy_to_device(rgcn_ctx* ctx, void* dev, const void* host, int64_t bytes);
+rgcn_status rgcn_copy_to_host(rgcn_ctx* ctx, void* host, const void* dev, int64_t bytes);
+/* HIP-event stopwatch on the context's stream (torch.cuda.Event cannot see this stream). */
+rgcn_status rgcn_timer_start(rgcn_ctx* ctx);
+rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises */
+
+/* Per-kernel profile: when enabled every launch is bracketed by HIP events on the context's stream.
+ * Records aggregate by kernel name; alg_bytes / alg_flops are the ALGORITHMIC bytes / flops of the
+ * launches ("roofline accounting"), summed over calls. */
+rgcn_status rgcn_profile_enable(rgcn_ctx* ctx, int32_t on);
+rgcn_status rgcn_profile_reset(rgcn_ctx* ctx);
+int32_t     rgcn_profile_count(rgcn_ctx* ctx); /* synchronises, aggregates; number of kernel names */
+rgcn_status rgcn_profile_get(rgcn_ctx* ctx, int32_t i, char* name, int32_t name_cap, int64_t* calls,
+                             double* total_ms, double* alg_bytes, double* alg_flops);
+
+/* ---- debugging aids used by the GPU parity tests ---------------------------------------------- */
+/* C[M,N] = op(A) . op(B) through the library's fp32-MFMA GEMM.  trans_a == 0: A is [M,K] row-major,
+ * else A is [K,M] row-major (used transposed); trans_b == 0: B is [K,N], else [N,K].
+ * split_k == 0 picks the split the encoder would use; > 1 forces that many K slabs. */
+rgcn_status rgcn_debug_gemm(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b, int32_t M, int32_t N,
+                            int32_t K, int32_t split_k, const float* a_host, const float* b_host,
+                            float* c_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGCN_H_ */

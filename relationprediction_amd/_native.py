@@ -1,0 +1,409 @@
+"""ctypes binding of librgcn.so (C ABI: include/rgcn.h).
+
+This is the only place Python crosses into native code -- the analogue of
+``session.run`` in the reference (code/optimization/optimize.py:81-88,
+code/model.py:56,69,81).  There is NO fallback: if the HIP library is missing
+or no GPU is visible, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librgcn.so")
+
+ABI_VERSION = 1
+KIND_BLOCK, KIND_BASIS = 0, 1
+NORM_INTENDED, NORM_TF_AS_EXECUTED, NORM_NONE = 0, 1, 2
+BUF_EXCHANGE, BUF_SELF, BUF_DSELF_EXCHANGE, BUF_INDEG, BUF_OUTDEG, BUF_ROWPTR = range(6)
+
+KINDS = {"block": KIND_BLOCK, "basis": KIND_BASIS}
+NORMS = {"intended": NORM_INTENDED, "tf_as_executed": NORM_TF_AS_EXECUTED, "none": NORM_NONE}
+
+
+class RgcnError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("librgcn status %d: %s" % (status, message))
+        self.status = status
+
+
+class RgcnConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("num_entities", C.c_int32),
+        ("num_relations", C.c_int32), ("dim", C.c_int32), ("num_layers", C.c_int32),
+        ("kind", C.c_int32), ("num_bases", C.c_int32), ("keep_prob", C.c_float),
+        ("norm_mode", C.c_int32), ("max_edges", C.c_int64), ("rank", C.c_int32),
+        ("world", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+_P = C.c_void_p
+_SIGS = {
+    "rgcn_abi_version": (C.c_int32, []),
+    "rgcn_create": (C.c_int32, [C.POINTER(RgcnConfig), C.POINTER(_P)]),
+    "rgcn_destroy": (C.c_int32, [_P]),
+    "rgcn_last_error": (C.c_char_p, [_P]),
+    "rgcn_sync": (C.c_int32, [_P]),
+    "rgcn_param_count": (C.c_int32, [_P]),
+    "rgcn_param_info": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "rgcn_set_param": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_get_param": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_get_grad": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_set_graph": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_set_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_forward": (C.c_int32, [_P, C.c_int32, C.c_uint64, _P]),
+    "rgcn_get_codes": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_get_activation": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_get_dropout_mask": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_codes_device": (_P, [_P]),
+    "rgcn_backward": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_backward_device": (C.c_int32, [_P, _P]),
+    "rgcn_step_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_uint64, _P]),
+    "rgcn_set_relation_owner": (C.c_int32, [_P, _P, C.c_int32]),
+    "rgcn_comm_unique_id": (C.c_int32, [_P]),
+    "rgcn_comm_init": (C.c_int32, [_P, _P]),
+    "rgcn_comm_allreduce_sum": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_forward_begin": (C.c_int32, [_P, C.c_int32, C.c_uint64, _P]),
+    "rgcn_forward_layer_partial": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_forward_layer_finish": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_backward_begin": (C.c_int32, [_P, _P]),
+    "rgcn_backward_layer_partial": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_backward_layer_finish": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_backward_end": (C.c_int32, [_P]),
+    "rgcn_read_buffer": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_write_buffer": (C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    "rgcn_device_alloc": (C.c_int32, [_P, C.c_int64, C.POINTER(_P)]),
+    "rgcn_device_free": (C.c_int32, [_P, _P]),
+    "rgcn_copy_to_device": (C.c_int32, [_P, _P, _P, C.c_int64]),
+    "rgcn_copy_to_host": (C.c_int32, [_P, _P, _P, C.c_int64]),
+    "rgcn_timer_start": (C.c_int32, [_P]),
+    "rgcn_timer_stop": (C.c_int32, [_P, C.POINTER(C.c_float)]),
+    "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_profile_reset": (C.c_int32, [_P]),
+    "rgcn_profile_count": (C.c_int32, [_P]),
+    "rgcn_profile_get": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rgcn_debug_gemm": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Names this binding expects librgcn.so to export (checked against include/rgcn.h in tests)."""
+    return sorted(_SIGS)
+
+
+def load_library(path=None):
+    """dlopen librgcn.so and attach prototypes.  Raises ImportError (never falls back) if missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            "%s not found: build the HIP library first (python -m relationprediction_amd.build, or "
+            "__graft_entry__.build()).  There is no CPU fallback." % p)
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rgcn_abi_version() != ABI_VERSION:
+        raise ImportError("librgcn.so ABI version %d != binding %d" % (lib.rgcn_abi_version(), ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A raw device allocation owned through the engine (no torch needed)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        engine._check(engine.lib.rgcn_device_alloc(engine.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes == self.nbytes, (arr.nbytes, self.nbytes)
+        self.engine._check(self.engine.lib.rgcn_copy_to_device(self.engine.ctx, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.engine._check(self.engine.lib.rgcn_copy_to_host(self.engine.ctx, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.engine.ctx is not None:
+            self.engine.lib.rgcn_device_free(self.engine.ctx, self.ptr)
+        self.ptr = None
+
+
+class Engine:
+    """One rgcn_ctx: the encoder (input layer + L relational graph-convolution layers) on one GPU."""
+
+    def __init__(self, num_entities, num_relations, dim, num_layers, kind, num_bases, keep_prob=0.8,
+                 norm_mode="intended", max_edges=0, device=0, rank=0, world=1):
+        self.lib = load_library()
+        self.ctx = None
+        cfg = RgcnConfig()
+        cfg.abi_version = ABI_VERSION
+        cfg.device = int(device)
+        cfg.num_entities = int(num_entities)
+        cfg.num_relations = int(num_relations)
+        cfg.dim = int(dim)
+        cfg.num_layers = int(num_layers)
+        cfg.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
+        cfg.num_bases = int(num_bases)
+        cfg.keep_prob = float(keep_prob)
+        cfg.norm_mode = NORMS[norm_mode] if isinstance(norm_mode, str) else int(norm_mode)
+        cfg.max_edges = int(max_edges)
+        cfg.rank = int(rank)
+        cfg.world = int(world)
+        cfg.reserved = 0
+        self.cfg = cfg
+        ctx = C.c_void_p()
+        st = self.lib.rgcn_create(C.byref(cfg), C.byref(ctx))
+        if st != 0:
+            raise RgcnError(st, (self.lib.rgcn_last_error(None) or b"").decode())
+        self.ctx = ctx
+        self.V, self.R, self.d, self.L = cfg.num_entities, cfg.num_relations, cfg.dim, cfg.num_layers
+        self.param_names, self.param_shapes = [], []
+        for i in range(self.lib.rgcn_param_count(self.ctx)):
+            name = C.create_string_buffer(64)
+            shape = (C.c_int64 * 4)()
+            nd = C.c_int32()
+            self._check(self.lib.rgcn_param_info(self.ctx, i, name, 64, shape, C.byref(nd)))
+            self.param_names.append(name.value.decode())
+            self.param_shapes.append(tuple(int(shape[k]) for k in range(nd.value)))
+
+    # -- plumbing
+    def _check(self, st):
+        if st != 0:
+            raise RgcnError(st, (self.lib.rgcn_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.rgcn_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._check(self.lib.rgcn_sync(self.ctx))
+
+    def _index(self, key):
+        return key if isinstance(key, int) else self.param_names.index(key)
+
+    # -- parameters
+    def set_param(self, key, value):
+        i = self._index(key)
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        if tuple(a.shape) != self.param_shapes[i]:
+            raise ValueError("%s: shape %s != %s" % (self.param_names[i], a.shape, self.param_shapes[i]))
+        self._check(self.lib.rgcn_set_param(self.ctx, i, _ptr(a), a.size))
+
+    def set_params(self, params):
+        for n in self.param_names:
+            self.set_param(n, params[n])
+
+    def get_param(self, key):
+        i = self._index(key)
+        out = np.empty(self.param_shapes[i], dtype=np.float32)
+        self._check(self.lib.rgcn_get_param(self.ctx, i, _ptr(out), out.size))
+        return out
+
+    def get_grad(self, key):
+        i = self._index(key)
+        out = np.empty(self.param_shapes[i], dtype=np.float32)
+        self._check(self.lib.rgcn_get_grad(self.ctx, i, _ptr(out), out.size))
+        return out
+
+    def get_grads(self):
+        return {n: self.get_grad(n) for n in self.param_names}
+
+    # -- graph
+    def set_graph(self, triples):
+        t = np.asarray(triples)
+        if t.size == 0:
+            t = np.zeros((0, 3), dtype=np.int32)
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("graph_edges must be [E,3]")
+        if t.dtype != np.int32:
+            # the reference feeds int64 numpy arrays into an int32 placeholder
+            if t.size and (t.min() < -2 ** 31 or t.max() >= 2 ** 31):
+                raise ValueError("ids do not fit int32")
+            t = t.astype(np.int32)
+        t = np.ascontiguousarray(t)
+        self._check(self.lib.rgcn_set_graph(self.ctx, _ptr(t), t.shape[0]))
+
+    def set_graph_device(self, dev_buffer, num_edges):
+        self._check(self.lib.rgcn_set_graph_device(self.ctx, dev_buffer.ptr, int(num_edges)))
+
+    def set_relation_owner(self, owner):
+        o = np.ascontiguousarray(owner, dtype=np.int32)
+        self._check(self.lib.rgcn_set_relation_owner(self.ctx, _ptr(o), o.size))
+
+    # -- forward / backward
+    def _masks(self, masks):
+        if masks is None:
+            return None, None
+        m = np.ascontiguousarray(np.stack([np.asarray(x) for x in masks]).astype(np.uint8))
+        if m.shape != (self.L, self.V, self.d):
+            raise ValueError("dropout masks must be [L,V,d]")
+        return m, _ptr(m)
+
+    def forward(self, train=True, seed=0, masks=None):
+        m, p = self._masks(masks)
+        self._check(self.lib.rgcn_forward(self.ctx, 1 if train else 0, C.c_uint64(seed), p))
+
+    def codes(self):
+        return self.activation(self.L)
+
+    def activation(self, layer):
+        out = np.empty((self.V, self.d), dtype=np.float32)
+        self._check(self.lib.rgcn_get_activation(self.ctx, int(layer), _ptr(out), out.size))
+        return out
+
+    def dropout_mask(self, layer):
+        out = np.empty((self.V, self.d), dtype=np.uint8)
+        self._check(self.lib.rgcn_get_dropout_mask(self.ctx, int(layer), _ptr(out), out.size))
+        return out
+
+    def backward(self, dcodes):
+        g = np.ascontiguousarray(dcodes, dtype=np.float32)
+        if g.shape != (self.V, self.d):
+            raise ValueError("dcodes must be [V,d]")
+        self._check(self.lib.rgcn_backward(self.ctx, _ptr(g), g.size))
+
+    def backward_device(self, dev_buffer):
+        self._check(self.lib.rgcn_backward_device(self.ctx, dev_buffer.ptr))
+
+    def step_device(self, triples_dev, num_edges, dcodes_dev, train=True, seed=0):
+        self._check(self.lib.rgcn_step_device(self.ctx, triples_dev.ptr, int(num_edges), 1 if train else 0,
+                                              C.c_uint64(seed), dcodes_dev.ptr))
+
+    # -- phase API (sharding exchange points)
+    def forward_begin(self, train=True, seed=0, masks=None):
+        m, p = self._masks(masks)
+        self._check(self.lib.rgcn_forward_begin(self.ctx, 1 if train else 0, C.c_uint64(seed), p))
+
+    def forward_layer_partial(self, l):
+        self._check(self.lib.rgcn_forward_layer_partial(self.ctx, l))
+
+    def forward_layer_finish(self, l):
+        self._check(self.lib.rgcn_forward_layer_finish(self.ctx, l))
+
+    def backward_begin(self, dcodes_dev):
+        self._check(self.lib.rgcn_backward_begin(self.ctx, dcodes_dev.ptr))
+
+    def backward_layer_partial(self, l):
+        self._check(self.lib.rgcn_backward_layer_partial(self.ctx, l))
+
+    def backward_layer_finish(self, l):
+        self._check(self.lib.rgcn_backward_layer_finish(self.ctx, l))
+
+    def backward_end(self):
+        self._check(self.lib.rgcn_backward_end(self.ctx))
+
+    def read_buffer(self, which):
+        if which in (BUF_INDEG, BUF_OUTDEG):
+            out = np.empty(self.V, dtype=np.int32)
+        elif which == BUF_ROWPTR:
+            out = np.empty(self.V + 1, dtype=np.int32)
+        elif which == BUF_DSELF_EXCHANGE:
+            out = np.empty((self.d, self.d), dtype=np.float32)
+        else:
+            out = np.empty((self.V, self.d), dtype=np.float32)
+        self._check(self.lib.rgcn_read_buffer(self.ctx, which, _ptr(out), out.nbytes))
+        return out
+
+    def write_buffer(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._check(self.lib.rgcn_write_buffer(self.ctx, which, _ptr(a), a.nbytes))
+
+    # -- communicator
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        st = lib.rgcn_comm_unique_id(buf)
+        if st != 0:
+            raise RgcnError(st, (lib.rgcn_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.rgcn_comm_init(self.ctx, buf))
+
+    def comm_allreduce_sum(self, dev_buffer, count):
+        self._check(self.lib.rgcn_comm_allreduce_sum(self.ctx, dev_buffer.ptr, int(count)))
+
+    # -- device memory / timing / profile
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    def timer_start(self):
+        self._check(self.lib.rgcn_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.rgcn_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.rgcn_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.rgcn_profile_reset(self.ctx))
+
+    def profile(self):
+        """[{name, calls, total_ms, alg_bytes, alg_flops}] aggregated per kernel name."""
+        out = []
+        n = self.lib.rgcn_profile_count(self.ctx)
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            calls = C.c_int64()
+            ms, by, fl = C.c_double(), C.c_double(), C.c_double()
+            self._check(self.lib.rgcn_profile_get(self.ctx, i, name, 64, C.byref(calls), C.byref(ms),
+                                                  C.byref(by), C.byref(fl)))
+            out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
+                        "alg_bytes": by.value, "alg_flops": fl.value})
+        return out
+
+    def debug_gemm(self, a, b, trans_a=False, trans_b=False, split_k=0):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        K, M = (a.shape if trans_a else a.shape[::-1])
+        N = b.shape[0] if trans_b else b.shape[1]
+        assert (b.shape[1] if trans_b else b.shape[0]) == K
+        out = np.empty((M, N), dtype=np.float32)
+        self._check(self.lib.rgcn_debug_gemm(self.ctx, int(trans_a), int(trans_b), M, N, K, int(split_k),
+                                             _ptr(a), _ptr(b), _ptr(out)))
+        return out

@@ -1,0 +1,103 @@
+// RCCL binding for the relation-sharded path (new: the reference is single-device).
+// One [V,d] fp32 sum-all-reduce per layer per direction over xGMI.  librccl.so.1 is dlopen'ed on
+// first use so that a single-GPU context never depends on it; if another RCCL client in the
+// process (e.g. torch) already mapped a librccl.so.1, the loader hands back that same image.
+#include <dlfcn.h>
+
+#include "rgcn_internal.h"
+
+namespace rgcn {
+
+namespace {
+
+typedef struct { char internal[128]; } nccl_unique_id;   // NCCL_UNIQUE_ID_BYTES = 128 (rccl.h:40-43)
+typedef void* nccl_comm_t;
+constexpr int kNcclSum = 0;        // rccl.h:448
+constexpr int kNcclFloat32 = 7;    // rccl.h:466
+
+struct Rccl {
+  void* handle = nullptr;
+  int (*GetUniqueId)(nccl_unique_id*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string error;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  return r;
+}
+
+bool load_rccl(std::string* err) {
+  Rccl& r = rccl();
+  if (r.handle) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    *err = std::string("cannot dlopen librccl.so.1: ") + dlerror();
+    return false;
+  }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+    *err = "librccl.so.1 lacks an expected nccl* symbol";
+    dlclose(r.handle);
+    r.handle = nullptr;
+    return false;
+  }
+  return true;
+}
+
+std::string nccl_err(const char* what, int code) {
+  return std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(code) : "?");
+}
+
+}  // namespace
+
+rgcn_status comm_unique_id(uint8_t id[128]) {
+  std::string err;
+  if (!load_rccl(&err)) { set_global_error(err); return RGCN_ERR_RCCL; }
+  nccl_unique_id u;
+  int rc = rccl().GetUniqueId(&u);
+  if (rc != 0) { set_global_error(nccl_err("ncclGetUniqueId", rc)); return RGCN_ERR_RCCL; }
+  memcpy(id, u.internal, 128);
+  return RGCN_OK;
+}
+
+rgcn_status comm_init(rgcn_ctx* c, const uint8_t id[128]) {
+  if (c->comm) RGCN_FAIL(c, RGCN_ERR_STATE, "communicator already initialised");
+  std::string err;
+  if (!load_rccl(&err)) RGCN_FAIL(c, RGCN_ERR_RCCL, err);
+  RGCN_HIP(c, hipSetDevice(c->cfg.device));
+  nccl_unique_id u;
+  memcpy(u.internal, id, 128);
+  nccl_comm_t comm = nullptr;
+  int rc = rccl().CommInitRank(&comm, c->world, u, c->rank);
+  if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclCommInitRank", rc));
+  c->comm = comm;
+  return RGCN_OK;
+}
+
+rgcn_status comm_allreduce(rgcn_ctx* c, float* buf, int64_t count) {
+  if (!c->comm) RGCN_FAIL(c, RGCN_ERR_STATE, "no communicator: call rgcn_comm_init first");
+  if (count <= 0) return RGCN_OK;
+  ProfScope ps(c, "rccl_allreduce", 8.0 * count, 0);
+  int rc = rccl().AllReduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, (nccl_comm_t)c->comm, c->stream);
+  if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclAllReduce", rc));
+  return RGCN_OK;
+}
+
+void comm_destroy(rgcn_ctx* c) {
+  if (c->comm && rccl().CommDestroy) rccl().CommDestroy((nccl_comm_t)c->comm);
+  c->comm = nullptr;
+}
+
+}  // namespace rgcn

@@ -1,0 +1,273 @@
+// HBM-bound row kernels of the encoder:
+//   * input layer  H0 = relu(W_emb + b_emb)            (code/encoders/affine_transform.py:63-83)
+//   * combine      out = act( dropout(base) + sum_{slots of row} msg )   -- the segmented reduction
+//     over incoming messages fused with the self-loop add, the self-loop dropout
+//     (message_gcn.py:60-64) and the relu (gcn_basis_concat.py:73-81 / gcn_basis.py:78-86);
+//     in the backward pass the same kernel sums the per-source message gradients, adds the
+//     self-loop gradient, applies relu' of the layer below and emits the dropout-scaled copy the
+//     self-loop GEMMs consume.
+// One group of 64/128/256 lanes walks one row with float4 accesses (d % 4 == 0) so every
+// global access is a full coalesced 16 B/lane stream; rows are independent => no atomics.
+#include "rgcn_internal.h"
+
+namespace rgcn {
+
+namespace {
+
+__device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
+  if (ds.mode == DROP_NONE) return 1.0f;
+  if (ds.mode == DROP_RNG) return drop_bits(ds.seed, ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
+  return ds.mask[idx] ? ds.inv_keep : 0.0f;
+}
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  using type = float4;
+};
+template <>
+struct VecT<1> {
+  using type = float;
+};
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// TPR lanes per row, 256 / TPR rows per workgroup.
+template <int VEC, int TPR>
+__global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
+  const int rows_per_block = 256 / TPR;
+  const int v = blockIdx.x * rows_per_block + threadIdx.x / TPR;
+  if (v >= a.V) return;
+  const int lane = threadIdx.x % TPR;
+  const int nvec = a.d / VEC;
+  int beg = 0, end = 0;
+  if (a.msg != nullptr) {
+    beg = a.row_ptr[v];
+    end = a.row_ptr[v + 1];
+  }
+  const bool base_valid = a.base != nullptr && v >= a.row_lo && v < a.row_hi;
+  for (int cidx = lane; cidx < nvec; cidx += TPR) {
+    const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    if (base_valid) {
+      vload<VEC>(a.base + off, acc);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] *= drop_scale(a.drop, off + k);
+    }
+    const float* mp = a.msg + (size_t)cidx * VEC;
+    int s = beg;
+    for (; s + 4 <= end; s += 4) {   // 4 independent 16-B loads in flight per lane
+      float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
+      vload<VEC>(mp + (size_t)(s + 0) * a.d, m0);
+      vload<VEC>(mp + (size_t)(s + 1) * a.d, m1);
+      vload<VEC>(mp + (size_t)(s + 2) * a.d, m2);
+      vload<VEC>(mp + (size_t)(s + 3) * a.d, m3);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
+    }
+    for (; s < end; ++s) {
+      float m0[VEC];
+      vload<VEC>(mp + (size_t)s * a.d, m0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+    }
+    if (a.gate != nullptr) {
+      float gt[VEC];
+      vload<VEC>(a.gate + off, gt);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = gt[k] > 0.0f ? acc[k] : 0.0f;
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaxf(acc[k], 0.0f);
+    }
+    vstore<VEC>(a.out + off, acc);
+    if (a.out2 != nullptr) {
+      float o2[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_scale(a.drop2, off + k);
+      vstore<VEC>(a.out2 + off, o2);
+    }
+  }
+}
+
+template <int VEC>
+__global__ void k_input_fwd(const float* __restrict__ W, const float* __restrict__ b,
+                            float* __restrict__ H, int64_t nvec_total, int d) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nvec_total; i += stride) {
+    const int64_t off = i * VEC;
+    const int col = (int)(off % d);
+    float w[VEC], bb[VEC], h[VEC];
+    vload<VEC>(W + off, w);
+    vload<VEC>(b + col, bb);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) h[k] = fmaxf(w[k] + bb[k], 0.0f);
+    vstore<VEC>(H + off, h);
+  }
+}
+
+__global__ void k_scale_dropout(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                DropSpec ds) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i] * drop_scale(ds, (size_t)i);
+}
+
+__global__ void k_relu_copy(const float* __restrict__ in, float* __restrict__ out, int64_t n, int relu) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float x = in[i];
+    out[i] = relu ? fmaxf(x, 0.0f) : x;
+  }
+}
+
+__global__ void k_materialize_mask(uint8_t* out, int64_t n, DropSpec ds) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = drop_scale(ds, (size_t)i) != 0.0f ? 1 : 0;
+}
+
+// column sums of a [rows, cols] matrix, deterministic two-stage reduction:
+// stage 1: block (bx, by) sums rows [by*RB, by*RB+RB) for 256 columns -> part[by][col]
+constexpr int kColRowsPerBlock = 128;
+__global__ void k_colsum_part(const float* __restrict__ in, float* __restrict__ part, int rows, int cols) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  const int r0 = blockIdx.y * kColRowsPerBlock;
+  const int r1 = min(rows, r0 + kColRowsPerBlock);
+  float acc = 0.0f;
+  for (int r = r0; r < r1; ++r) acc += in[(size_t)r * cols + col];
+  part[(size_t)blockIdx.y * cols + col] = acc;
+}
+__global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int nparts, int cols) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  float acc = 0.0f;
+  for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * cols + col];
+  out[col] = acc;
+}
+
+int grid_for(int64_t n, int threads) {
+  int64_t b = (n + threads - 1) / threads;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+DropSpec make_drop(const rgcn_ctx* c, int layer, bool active) {
+  DropSpec ds;
+  ds.mode = DROP_NONE;
+  ds.layer = (uint32_t)layer;
+  ds.thresh = (uint32_t)((double)c->cfg.keep_prob * 16777216.0);
+  ds.inv_keep = 1.0f / c->cfg.keep_prob;
+  ds.seed = c->seed;
+  ds.mask = nullptr;
+  if (active && c->fwd_train && layer >= 1 && layer <= c->L) {
+    if (c->explicit_masks) {
+      ds.mode = DROP_MASK;
+      ds.mask = c->masks + (size_t)(layer - 1) * c->V * c->d;
+    } else {
+      ds.mode = DROP_RNG;
+    }
+  }
+  return ds;
+}
+
+rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes) {
+  if (a.V <= 0) return RGCN_OK;
+  const bool vec4 = (a.d % 4 == 0) && aligned16(a.out) && aligned16(a.base) && aligned16(a.msg) &&
+                    aligned16(a.gate) && aligned16(a.out2);
+  const int nvec = vec4 ? a.d / 4 : a.d;
+  const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
+  const int rows_per_block = 256 / tpr;
+  dim3 grid((a.V + rows_per_block - 1) / rows_per_block), block(256);
+  ProfScope ps(c, tag, alg_bytes, 0);
+#define RGCN_LAUNCH_COMBINE(VEC, TPR) \
+  hipLaunchKernelGGL((k_combine<VEC, TPR>), grid, block, 0, c->stream, a)
+  if (vec4) {
+    if (tpr == 64) RGCN_LAUNCH_COMBINE(4, 64);
+    else if (tpr == 128) RGCN_LAUNCH_COMBINE(4, 128);
+    else RGCN_LAUNCH_COMBINE(4, 256);
+  } else {
+    if (tpr == 64) RGCN_LAUNCH_COMBINE(1, 64);
+    else if (tpr == 128) RGCN_LAUNCH_COMBINE(1, 128);
+    else RGCN_LAUNCH_COMBINE(1, 256);
+  }
+#undef RGCN_LAUNCH_COMBINE
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status input_forward(rgcn_ctx* c) {
+  const int64_t n = (int64_t)c->V * c->d;
+  ProfScope ps(c, "input_fwd", 8.0 * n, 0);
+  if (c->d % 4 == 0) {
+    hipLaunchKernelGGL((k_input_fwd<4>), dim3(grid_for(n / 4, 256)), dim3(256), 0, c->stream, c->w_emb,
+                       c->b_emb, c->H[0], n / 4, c->d);
+  } else {
+    hipLaunchKernelGGL((k_input_fwd<1>), dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->w_emb,
+                       c->b_emb, c->H[0], n, c->d);
+  }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds) {
+  const int64_t n = (int64_t)c->V * c->d;
+  ProfScope ps(c, "top_grad_dropout", 8.0 * n, 0);
+  hipLaunchKernelGGL(k_scale_dropout, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, in, out, n, ds);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status relu_copy(rgcn_ctx* c, const float* in, float* out, int64_t n, int relu) {
+  ProfScope ps(c, "activation", 8.0 * n, 0);
+  hipLaunchKernelGGL(k_relu_copy, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, in, out, n, relu);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, int64_t n) {
+  hipLaunchKernelGGL(k_materialize_mask, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, out_dev, n, ds);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols) {
+  const int nparts = (rows + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  ProfScope ps(c, "bias_grad_colsum", 4.0 * rows * cols, 0);
+  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 255) / 256, nparts), dim3(256), 0, c->stream, in,
+                     c->colsum_part, rows, cols);
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, c->stream,
+                     c->colsum_part, out, nparts, cols);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+}  // namespace rgcn

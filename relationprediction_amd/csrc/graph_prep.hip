@@ -1,0 +1,305 @@
+// Device-side graph preparation: everything the reference derives from the `graph_edges`
+// placeholder inside session.run (code/extras/graph_representations.py:21-27 edge split,
+// :82-93 / :122-133 'global' normalisation = per-row softmax of ones) plus the layouts the HIP
+// kernels want:
+//
+//   * indeg / outdeg over ALL fed edges (normalisation is global, also under relation sharding);
+//   * the MESSAGE list: 2E messages (m <  E: forward  message of edge m, dst = object,  src = subject,
+//                                     rel2 = r,     norm = 1/indeg[object];
+//                                    m >= E: backward message of edge m-E, dst = subject, src = object,
+//                                     rel2 = R + r, norm = 1/outdeg[subject]),
+//     stably sorted by rel2 ("per-relation CSR": rel_ptr) and cut into chunks of <= `chunk`
+//     messages of one relation (chunk_ptr) -- the unit of work of the block-diagonal kernels;
+//   * the INCIDENCE CSR: 2E incidences (i < E: edge i seen from its object, i >= E: edge i-E seen
+//     from its subject) stably sorted by vertex (row_ptr).  Message m is written to slot pos[m] in
+//     the forward pass (rows = destinations) and to slot pos[(m+E) mod 2E] in the backward pass
+//     (rows = sources): one sort serves both directions.
+//
+// All of it is stream-ordered with no host synchronisation, so a step can be graph-captured.
+// Sorting uses rocPRIM's stable LSD radix sort (deterministic order => deterministic fp32 sums).
+#include "rgcn_internal.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace rgcn {
+
+namespace {
+
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 16;
+
+__global__ void k_hist(const int32_t* __restrict__ tri, int E, int V, int R,
+                       const int32_t* __restrict__ owner, int rank, int32_t* indeg, int32_t* outdeg,
+                       int32_t* cnt, int32_t* relcnt, int32_t* errflag) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
+  if ((unsigned)s >= (unsigned)V || (unsigned)o >= (unsigned)V || (unsigned)r >= (unsigned)R) {
+    atomicOr(errflag, 1);
+    return;
+  }
+  atomicAdd(&indeg[o], 1);
+  atomicAdd(&outdeg[s], 1);
+  if (owner[r] == rank) {
+    atomicAdd(&cnt[o], 1);
+    atomicAdd(&cnt[s], 1);
+    atomicAdd(&relcnt[r], 1);
+    atomicAdd(&relcnt[R + r], 1);
+  }
+}
+
+struct ScanJob {
+  const int32_t* in;
+  int32_t* out;     // n + 1 entries
+  int32_t n;
+  int32_t div;      // 0: identity, else value -> ceil(value / div)
+};
+struct ScanJobs {
+  ScanJob j[5];
+};
+
+// One workgroup per job; exclusive scan with carry over tiles of 1024 x 16 elements.
+__global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
+  const ScanJob job = jobs.j[blockIdx.x];
+  __shared__ int32_t wsum[kScanThreads / 64];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < job.n; base += kScanThreads * kScanItems) {
+    int32_t v[kScanItems];
+    int32_t tsum = 0;
+    const int start = base + tid * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      int idx = start + k;
+      int32_t x = idx < job.n ? job.in[idx] : 0;
+      if (job.div) x = (x + job.div - 1) / job.div;
+      v[k] = tsum;   // exclusive within the thread
+      tsum += x;
+    }
+    // inclusive wave scan of tsum
+    int32_t incl = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int32_t wbase = 0;
+    for (int w = 0; w < wid; ++w) wbase += wsum[w];
+    int32_t total = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) total += wsum[w];
+    const int32_t carry = carry_s;
+    const int32_t tbase = carry + wbase + incl - tsum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      int idx = start + k;
+      if (idx < job.n) job.out[idx] = tbase + v[k];
+    }
+    __syncthreads();
+    if (tid == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) job.out[job.n] = carry_s;
+}
+
+__global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
+                       const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
+                       uint32_t* keyr, int32_t* valr) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * E) return;
+  const bool fwd = i < E;
+  const int e = fwd ? i : i - E;
+  int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
+  bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
+  bool owned = ok && owner[r] == rank;
+  keyv[i] = owned ? (uint32_t)(fwd ? o : s) : (uint32_t)V;   // incidence i sits at this vertex
+  valv[i] = i;
+  keyr[i] = owned ? (uint32_t)(fwd ? r : R + r) : (uint32_t)(2 * R);
+  valr[i] = i;
+}
+
+__global__ void k_pos(const int32_t* __restrict__ permv, int n, int32_t* pos) {
+  int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < n) pos[permv[slot]] = slot;
+}
+
+__device__ __forceinline__ int upper_bound_dev(const int32_t* a, int n, int x) {
+  // first index i in [0,n) with a[i] > x
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int R, int norm_mode,
+                             const int32_t* __restrict__ permr, const int32_t* __restrict__ rel_ptr,
+                             const int32_t* __restrict__ pos, const int32_t* __restrict__ indeg,
+                             const int32_t* __restrict__ outdeg, const int32_t* __restrict__ cum_in,
+                             const int32_t* __restrict__ cum_out, int32_t* m_src, int32_t* m_dst,
+                             int32_t* m_dslot, int32_t* m_sslot, float* m_norm) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * E) return;
+  if (j >= rel_ptr[2 * R]) return;    // beyond the owned messages
+  const int m = permr[j];
+  const bool fwd = m < E;
+  const int e = fwd ? m : m - E;
+  const int s = tri[3 * e], o = tri[3 * e + 2];
+  const int src = fwd ? s : o, dst = fwd ? o : s;
+  float norm;
+  if (norm_mode == RGCN_NORM_NONE) {
+    norm = 1.0f;
+  } else if (norm_mode == RGCN_NORM_INTENDED) {
+    norm = 1.0f / (float)(fwd ? indeg[o] : outdeg[s]);
+  } else {
+    // tf_as_executed: value k of the sorted-row softmax is attached to edge k:
+    // the k-th smallest row index is the vertex v with cum[v] <= k < cum[v+1].
+    const int32_t* cum = fwd ? cum_in : cum_out;
+    const int v = upper_bound_dev(cum, V + 1, e) - 1;
+    norm = 1.0f / (float)(fwd ? indeg[v] : outdeg[v]);
+  }
+  m_src[j] = src;
+  m_dst[j] = dst;
+  m_norm[j] = norm;
+  m_dslot[j] = pos[m];
+  m_sslot[j] = pos[fwd ? m + E : m - E];
+}
+
+int bits_for(uint32_t max_value) {
+  int b = 1;
+  while (b < 32 && (1ull << b) <= max_value) ++b;
+  return b;
+}
+
+template <class T>
+rgcn_status dalloc(rgcn_ctx* c, T** p, size_t n) {
+  RGCN_HIP(c, hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  return RGCN_OK;
+}
+
+}  // namespace
+
+rgcn_status graph_alloc(rgcn_ctx* c) {
+  GraphBufs& g = c->g;
+  const size_t V = c->V, R2 = 2 * (size_t)c->R, M = 2 * (size_t)c->cfg.max_edges;
+  RGCN_TRY(dalloc(c, &g.triples, 3 * (size_t)c->cfg.max_edges));
+  g.counters_bytes = (3 * V + R2) * sizeof(int32_t);
+  RGCN_TRY(dalloc(c, &g.counters, 3 * V + R2));
+  g.indeg = g.counters;
+  g.outdeg = g.counters + V;
+  g.cnt = g.counters + 2 * V;
+  g.relcnt = g.counters + 3 * V;
+  RGCN_TRY(dalloc(c, &g.row_ptr, V + 1));
+  RGCN_TRY(dalloc(c, &g.rel_ptr, R2 + 1));
+  RGCN_TRY(dalloc(c, &g.chunk_ptr, R2 + 1));
+  RGCN_TRY(dalloc(c, &g.cum_in, V + 1));
+  RGCN_TRY(dalloc(c, &g.cum_out, V + 1));
+  RGCN_TRY(dalloc(c, &g.keyv, M));
+  RGCN_TRY(dalloc(c, &g.keyv_s, M));
+  RGCN_TRY(dalloc(c, &g.keyr, M));
+  RGCN_TRY(dalloc(c, &g.keyr_s, M));
+  RGCN_TRY(dalloc(c, &g.valv, M));
+  RGCN_TRY(dalloc(c, &g.permv, M));
+  RGCN_TRY(dalloc(c, &g.valr, M));
+  RGCN_TRY(dalloc(c, &g.permr, M));
+  RGCN_TRY(dalloc(c, &g.pos, M));
+  RGCN_TRY(dalloc(c, &g.m_src, M));
+  RGCN_TRY(dalloc(c, &g.m_dst, M));
+  RGCN_TRY(dalloc(c, &g.m_dslot, M));
+  RGCN_TRY(dalloc(c, &g.m_sslot, M));
+  RGCN_TRY(dalloc(c, &g.m_norm, M));
+  RGCN_TRY(dalloc(c, &g.owner, (size_t)c->R));
+  RGCN_TRY(dalloc(c, &g.errflag, 1));
+  RGCN_HIP(c, hipMemsetAsync(g.owner, 0, sizeof(int32_t) * (size_t)(c->R ? c->R : 1), c->stream));
+  RGCN_HIP(c, hipMemsetAsync(g.errflag, 0, sizeof(int32_t), c->stream));
+  RGCN_HIP(c, hipMemsetAsync(g.row_ptr, 0, sizeof(int32_t) * (V + 1), c->stream));
+  RGCN_HIP(c, hipMemsetAsync(g.rel_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
+  RGCN_HIP(c, hipMemsetAsync(g.chunk_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
+  // temp storage for the larger of the two sorts (same element count, different bit ranges)
+  size_t t1 = 0, t2 = 0;
+  if (M > 0) {
+    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, g.keyv, g.keyv_s, g.valv, g.permv, M, 0,
+                                          bits_for((uint32_t)c->V), c->stream));
+    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, g.keyr, g.keyr_s, g.valr, g.permr, M, 0,
+                                          bits_for((uint32_t)(2 * c->R)), c->stream));
+  }
+  g.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+  RGCN_HIP(c, hipMalloc(&g.sort_tmp, g.sort_tmp_bytes));
+  return RGCN_OK;
+}
+
+void graph_free(rgcn_ctx* c) {
+  GraphBufs& g = c->g;
+  void* ptrs[] = {g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
+                  g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
+                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.owner, g.errflag, g.sort_tmp};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  g = GraphBufs();
+}
+
+rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
+  GraphBufs& g = c->g;
+  const int E = (int)E64, V = c->V, R = c->R;
+  g.cur = tri;
+  g.E = E;
+  g.ready = false;
+  c->fwd_done = false;
+  RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
+  const int T = 256;
+  if (E > 0) {
+    ProfScope ps(c, "prep_hist", 12.0 * E, 0);
+    hipLaunchKernelGGL(k_hist, dim3((E + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
+                       c->rank, g.indeg, g.outdeg, g.cnt, g.relcnt, g.errflag);
+  }
+  {
+    ScanJobs jobs;
+    jobs.j[0] = {g.cnt, g.row_ptr, V, 0};
+    jobs.j[1] = {g.relcnt, g.rel_ptr, 2 * R, 0};
+    jobs.j[2] = {g.relcnt, g.chunk_ptr, 2 * R, c->chunk};
+    jobs.j[3] = {g.indeg, g.cum_in, V, 0};
+    jobs.j[4] = {g.outdeg, g.cum_out, V, 0};
+    const int njobs = (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) ? 5 : 3;
+    ProfScope ps(c, "prep_scan", 8.0 * (V + 4 * R), 0);
+    hipLaunchKernelGGL(k_exscan, dim3(njobs), dim3(kScanThreads), 0, c->stream, jobs);
+  }
+  if (E > 0) {
+    const int M = 2 * E;
+    {
+      ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
+      hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
+                         c->rank, g.keyv, g.valv, g.keyr, g.valr);
+    }
+    {
+      ProfScope ps(c, "prep_sort_vertex", 16.0 * M, 0);
+      size_t tb = g.sort_tmp_bytes;
+      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp, tb, g.keyv, g.keyv_s, g.valv, g.permv,
+                                            (size_t)M, 0, bits_for((uint32_t)V), c->stream));
+    }
+    {
+      ProfScope ps(c, "prep_sort_relation", 16.0 * M, 0);
+      size_t tb = g.sort_tmp_bytes;
+      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp, tb, g.keyr, g.keyr_s, g.valr, g.permr,
+                                            (size_t)M, 0, bits_for((uint32_t)(2 * R)), c->stream));
+    }
+    {
+      ProfScope ps(c, "prep_pos", 8.0 * M, 0);
+      hipLaunchKernelGGL(k_pos, dim3((M + T - 1) / T), dim3(T), 0, c->stream, g.permv, M, g.pos);
+    }
+    {
+      ProfScope ps(c, "prep_build_msgs", 12.0 * E + 28.0 * M, 0);
+      hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
+                         c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
+                         g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm);
+    }
+  }
+  RGCN_HIP(c, hipGetLastError());
+  g.ready = true;
+  return RGCN_OK;
+}
+
+}  // namespace rgcn

@@ -1,0 +1,754 @@
+// C ABI of librgcn.so (include/rgcn.h) and the per-layer orchestration of the encoder:
+//   forward  (MessageGcn.compute_vertex_embeddings, code/encoders/message_gcns/message_gcn.py:49-79)
+//   backward (tf.gradients(loss, weights), code/optimization/abstract.py:117-118; formulas SURVEY 8a a15)
+#include <mutex>
+#include <new>
+
+#include "rgcn_internal.h"
+
+namespace rgcn {
+
+static std::mutex g_err_mu;
+static std::string g_err;
+void set_global_error(const std::string& s) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_err = s;
+}
+
+// ---------------------------------------------------------------- profiling
+ProfScope::ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops) : c(ctx), idx(-1) {
+  if (!c->prof_on) return;
+  ProfRec r;
+  r.name = name;
+  r.bytes = bytes;
+  r.flops = flops;
+  for (int k = 0; k < 2; ++k) {
+    hipEvent_t e = nullptr;
+    if (!c->event_pool.empty()) {
+      e = c->event_pool.back();
+      c->event_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      return;
+    }
+    (k == 0 ? r.e0 : r.e1) = e;
+  }
+  (void)hipEventRecord(r.e0, c->stream);
+  c->prof.push_back(r);
+  idx = (int)c->prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, c->stream);
+}
+
+static rgcn_status profile_collect(rgcn_ctx* c) {
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  for (ProfRec& r : c->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    ProfAgg* a = nullptr;
+    for (ProfAgg& x : c->prof_agg)
+      if (x.name == r.name) { a = &x; break; }
+    if (!a) {
+      c->prof_agg.push_back({r.name, 0, 0.0, 0.0, 0.0});
+      a = &c->prof_agg.back();
+    }
+    a->calls += 1;
+    a->ms += ms;
+    a->bytes += r.bytes;
+    a->flops += r.flops;
+    c->event_pool.push_back(r.e0);
+    c->event_pool.push_back(r.e1);
+  }
+  c->prof.clear();
+  return RGCN_OK;
+}
+
+// ---------------------------------------------------------------- helpers
+template <class T>
+static rgcn_status dmalloc(rgcn_ctx* c, T** p, size_t n, bool zero = true) {
+  *p = nullptr;
+  hipError_t e = hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
+  if (e != hipSuccess) {
+    c->err = std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? RGCN_ERR_NOMEM : RGCN_ERR_HIP;
+  }
+  if (zero) RGCN_HIP(c, hipMemsetAsync(*p, 0, (n ? n : 1) * sizeof(T), c->stream));
+  return RGCN_OK;
+}
+
+static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_list<int64_t> shape,
+                      float* val, float* grad, int layout) {
+  Param p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.count = 1;
+  int i = 0;
+  for (int64_t s : shape) { p.shape[i++] = s; p.count *= s; }
+  for (; i < 4; ++i) p.shape[i] = 1;
+  p.val = val;
+  p.grad = grad;
+  p.layout = layout;
+  c->params.push_back(p);
+}
+
+static int auto_split_k(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 192) return 1;
+  int s = (512 + tiles - 1) / tiles;
+  const int max_by_k = (K + 127) / 128;   // at least 128 of K per slab
+  if (s > max_by_k) s = max_by_k;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+
+static rgcn_status check_dev_flag(rgcn_ctx* c) {
+  int32_t flag = 0;
+  RGCN_HIP(c, hipMemcpyAsync(&flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  if (flag) {
+    RGCN_HIP(c, hipMemsetAsync(c->g.errflag, 0, sizeof(int32_t), c->stream));
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "graph_edges contains a vertex id outside [0,EntityCount) or a "
+                                   "relation id outside [0,RelationCount)");
+  }
+  return RGCN_OK;
+}
+
+static rgcn_status to_host(rgcn_ctx* c, void* host, const void* dev, size_t bytes) {
+  RGCN_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  return RGCN_OK;
+}
+static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes) {
+  RGCN_HIP(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));   // host memory is borrowed for the call only
+  return RGCN_OK;
+}
+
+static void free_all(rgcn_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  comm_destroy(c);
+  graph_free(c);
+  auto F = [](void* p) { if (p) (void)hipFree(p); };
+  F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb);
+  for (LayerBufs& lb : c->layers) {
+    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);
+  }
+  for (float* h : c->H) F(h);
+  F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
+  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own);
+  for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->t0) (void)hipEventDestroy(c->t0);
+  if (c->t1) (void)hipEventDestroy(c->t1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static rgcn_status create_impl(rgcn_ctx* c) {
+  const rgcn_config& f = c->cfg;
+  if (f.abi_version != RGCN_ABI_VERSION) RGCN_FAIL(c, RGCN_ERR_INVALID, "abi_version mismatch");
+  if (f.num_entities <= 0 || f.num_relations <= 0 || f.dim <= 0 || f.num_layers <= 0 || f.num_bases <= 0)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "EntityCount, RelationCount, dimension, NumberOfLayers and "
+                                   "NumberOfBasisFunctions must be positive");
+  if (!(f.keep_prob > 0.0f && f.keep_prob <= 1.0f)) RGCN_FAIL(c, RGCN_ERR_INVALID, "DropoutKeepProbability must be in (0,1]");
+  if (f.kind != RGCN_KIND_BLOCK && f.kind != RGCN_KIND_BASIS) RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown kind");
+  if (f.norm_mode < 0 || f.norm_mode > 2) RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown norm_mode");
+  if (f.world < 1 || f.rank < 0 || f.rank >= f.world) RGCN_FAIL(c, RGCN_ERR_INVALID, "need 0 <= rank < world");
+  if (f.max_edges < 0 || f.max_edges > (int64_t)500 * 1000 * 1000) RGCN_FAIL(c, RGCN_ERR_INVALID, "max_edges out of range");
+  if (f.reserved != 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "reserved must be 0");
+  c->V = f.num_entities; c->R = f.num_relations; c->d = f.dim; c->L = f.num_layers; c->kind = f.kind;
+  c->rank = f.rank; c->world = f.world;
+  if ((int64_t)c->V * c->d > (int64_t)1 << 31 || 2 * f.max_edges * (int64_t)c->d > ((int64_t)1 << 40))
+    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "problem too large for this build");
+  if (c->kind == RGCN_KIND_BLOCK) {
+    c->nb = f.num_bases;
+    if (c->d % c->nb != 0)
+      RGCN_FAIL(c, RGCN_ERR_INVALID, "InternalEncoderDimension must be divisible by NumberOfBasisFunctions "
+                                     "(the reference silently mis-groups otherwise: gcn_basis_concat.py:15,42)");
+    c->sd = c->d / c->nb;
+    RGCN_TRY(block_geometry(c));
+  } else {
+    c->B = f.num_bases;
+    if (c->B > 64) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "NumberOfBasisFunctions > 64 (basis)");
+  }
+  c->row_lo = (int)((int64_t)c->rank * c->V / c->world);
+  c->row_hi = (int)((int64_t)(c->rank + 1) * c->V / c->world);
+
+  RGCN_HIP(c, hipSetDevice(f.device));
+  RGCN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  RGCN_HIP(c, hipEventCreate(&c->t0));
+  RGCN_HIP(c, hipEventCreate(&c->t1));
+
+  const size_t V = c->V, d = c->d, R = c->R, Vd = V * d;
+  RGCN_TRY(dmalloc(c, &c->w_emb, Vd));
+  RGCN_TRY(dmalloc(c, &c->g_emb, Vd));
+  RGCN_TRY(dmalloc(c, &c->b_emb, d));
+  RGCN_TRY(dmalloc(c, &c->gb_emb, d));
+  add_param(c, "W_emb", {(int64_t)V, (int64_t)d}, c->w_emb, c->g_emb, LAYOUT_PLAIN);
+  add_param(c, "b_emb", {(int64_t)d}, c->b_emb, c->gb_emb, LAYOUT_PLAIN);
+  c->layers.resize(c->L + 1);
+  for (int l = 1; l <= c->L; ++l) {
+    LayerBufs& lb = c->layers[l];
+    const std::string sl = std::to_string(l);
+    if (c->kind == RGCN_KIND_BLOCK) {
+      const size_t per_dir = R * c->nb * c->sd * c->sd;
+      RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));
+      RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
+      add_param(c, "W_f" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel, lb.grel, LAYOUT_BLOCK_T);
+      add_param(c, "W_b" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel + per_dir, lb.grel + per_dir, LAYOUT_BLOCK_T);
+    } else {
+      const size_t per_dir = (size_t)c->B * d * d;
+      RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));
+      RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
+      RGCN_TRY(dmalloc(c, &lb.coef, 2 * R * c->B));
+      RGCN_TRY(dmalloc(c, &lb.gcoef, 2 * R * c->B));
+      add_param(c, "W_f" + sl, {(int64_t)d, c->B, (int64_t)d}, lb.wrel, lb.grel, LAYOUT_BASIS_T);
+      add_param(c, "W_b" + sl, {(int64_t)d, c->B, (int64_t)d}, lb.wrel + per_dir, lb.grel + per_dir, LAYOUT_BASIS_T);
+      add_param(c, "C_f" + sl, {(int64_t)R, c->B}, lb.coef, lb.gcoef, LAYOUT_PLAIN);
+      add_param(c, "C_b" + sl, {(int64_t)R, c->B}, lb.coef + R * c->B, lb.gcoef + R * c->B, LAYOUT_PLAIN);
+    }
+    RGCN_TRY(dmalloc(c, &lb.wself, d * d));
+    RGCN_TRY(dmalloc(c, &lb.gwself, d * d));
+    RGCN_TRY(dmalloc(c, &lb.bias, d));
+    RGCN_TRY(dmalloc(c, &lb.gbias, d));
+    add_param(c, "W_self" + sl, {(int64_t)d, (int64_t)d}, lb.wself, lb.gwself, LAYOUT_PLAIN);
+    add_param(c, "b" + sl, {(int64_t)d}, lb.bias, lb.gbias, LAYOUT_PLAIN);
+  }
+  c->H.assign(c->L + 1, nullptr);
+  for (int l = 0; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->H[l], Vd));
+  RGCN_TRY(dmalloc(c, &c->self_buf, Vd));
+  if (c->world > 1) RGCN_TRY(dmalloc(c, &c->exch, Vd));
+  for (int k = 0; k < 2; ++k) {
+    RGCN_TRY(dmalloc(c, &c->dbuf[k], Vd));
+    RGCN_TRY(dmalloc(c, &c->dsbuf[k], Vd));
+  }
+  const size_t M = 2 * (size_t)f.max_edges;
+  size_t slab = 64 * d * d;   // split-K slabs of the dW_self GEMM
+  if (c->kind == RGCN_KIND_BLOCK) {
+    RGCN_TRY(dmalloc(c, &c->msgbuf, (M ? M : 1) * d, false));
+    const size_t per_rel = (size_t)c->sd * c->sd * c->nb;
+    const size_t dw = ((M + c->chunk - 1) / c->chunk + 2 * R) * per_rel;
+    if (dw > slab) slab = dw;
+  } else {
+    const size_t zc = 2 * (size_t)c->B * d;
+    RGCN_TRY(dmalloc(c, &c->msgbuf, V * zc));
+    RGCN_TRY(dmalloc(c, &c->msgbuf2, V * zc));
+    const size_t s2 = 64 * zc * d;
+    if (s2 > slab) slab = s2;
+  }
+  c->slab_floats = slab;
+  RGCN_TRY(dmalloc(c, &c->slab, slab));
+  size_t stage = Vd;
+  for (const Param& p : c->params)
+    if ((size_t)p.count > stage) stage = (size_t)p.count;
+  c->stage_floats = stage;
+  RGCN_TRY(dmalloc(c, &c->stage, stage, false));
+  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 127) / 128) * d));
+  RGCN_TRY(graph_alloc(c));
+  {
+    std::vector<int32_t> owner(c->R);
+    for (int r = 0; r < c->R; ++r) owner[r] = r % c->world;
+    RGCN_TRY(to_dev(c, c->g.owner, owner.data(), sizeof(int32_t) * owner.size()));
+  }
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  return RGCN_OK;
+}
+
+// ---------------------------------------------------------------- layout conversion
+static rgcn_status param_upload(rgcn_ctx* c, const Param& p, float* dst, const float* host) {
+  if (p.layout == LAYOUT_PLAIN) return to_dev(c, dst, host, sizeof(float) * p.count);
+  RGCN_TRY(to_dev(c, c->stage, host, sizeof(float) * p.count));
+  if (p.layout == LAYOUT_BLOCK_T) RGCN_TRY(block_to_device_layout(c, c->stage, dst, c->R));
+  else RGCN_TRY(basis_to_device_layout(c, c->stage, dst));
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  return RGCN_OK;
+}
+static rgcn_status param_download(rgcn_ctx* c, const Param& p, const float* src, float* host) {
+  if (p.layout == LAYOUT_PLAIN) return to_host(c, host, src, sizeof(float) * p.count);
+  if (p.layout == LAYOUT_BLOCK_T) RGCN_TRY(block_from_device_layout(c, src, c->stage, c->R));
+  else RGCN_TRY(basis_from_device_layout(c, src, c->stage));
+  return to_host(c, host, c->stage, sizeof(float) * p.count);
+}
+
+// ---------------------------------------------------------------- forward
+static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks_host) {
+  if (!c->g.ready) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_forward before rgcn_set_graph");
+  c->fwd_done = false;
+  c->fwd_train = train ? 1 : 0;
+  c->seed = seed;
+  c->explicit_masks = false;
+  if (train && masks_host) {
+    const size_t n = (size_t)c->L * c->V * c->d;
+    if (!c->masks) RGCN_TRY(dmalloc(c, &c->masks, n, false));
+    RGCN_TRY(to_dev(c, c->masks, masks_host, n));
+    c->explicit_masks = true;
+  }
+  return input_forward(c);
+}
+
+static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
+  if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
+  const float* Hin = c->H[l - 1];
+  const int d = c->d, V = c->V;
+  const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
+  // self-loop: S = H . W_self  (rows of this rank's shard)
+  RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                    c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+  float* dst = c->world > 1 ? c->exch : c->H[l];
+  const double Mmsg = 2.0 * c->g.E / c->world;
+  if (c->kind == RGCN_KIND_BLOCK) {
+    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    CombineArgs a;
+    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
+    a.row_ptr = c->g.row_ptr; a.gate = nullptr; a.V = V; a.d = d;
+    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
+    a.row_lo = lo; a.row_hi = hi;
+    a.drop = make_drop(c, l, true);
+    a.drop2 = make_drop(c, l, false);
+    RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
+  } else {
+    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
+  }
+  return RGCN_OK;
+}
+
+static rgcn_status fwd_layer_finish(rgcn_ctx* c, int l) {
+  if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
+  if (c->world > 1)
+    RGCN_TRY(relu_copy(c, c->exch, c->H[l], (int64_t)c->V * c->d, l < c->L ? 1 : 0));
+  if (l == c->L) c->fwd_done = true;
+  return RGCN_OK;
+}
+
+// ---------------------------------------------------------------- backward
+static rgcn_status bwd_begin(rgcn_ctx* c, const float* dcodes_dev) {
+  if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward needs a completed rgcn_forward on the current graph");
+  if (!dcodes_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "dcodes is NULL");
+  c->bwd_layer = c->L;
+  c->bwd_D = dcodes_dev;
+  DropSpec ds = make_drop(c, c->L, true);
+  if (ds.mode != DROP_NONE) {
+    RGCN_TRY(scale_dropout(c, dcodes_dev, c->dsbuf[c->L & 1], ds));
+    c->bwd_dS = c->dsbuf[c->L & 1];
+  } else {
+    c->bwd_dS = dcodes_dev;
+  }
+  return RGCN_OK;
+}
+
+static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
+  if (l != c->bwd_layer || l < 1) RGCN_FAIL(c, RGCN_ERR_STATE, "backward layers must run L..1 in order");
+  const float* Hin = c->H[l - 1];
+  const int d = c->d, V = c->V;
+  const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
+  const int rows = hi - lo;
+  LayerBufs& lb = c->layers[l];
+  // dW_self = H_in^T . dS   (K = rows of this shard, split over K)
+  RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                    c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  // G = dS . W_self^T
+  RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                    c->self_buf + (size_t)lo * d, d, 1));
+  if (c->kind != RGCN_KIND_BLOCK) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
+  RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
+  const double Mmsg = 2.0 * c->g.E / c->world;
+  CombineArgs a;
+  a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr; a.row_ptr = c->g.row_ptr;
+  a.V = V; a.d = d; a.relu = 0; a.row_lo = lo; a.row_hi = hi;
+  a.drop = make_drop(c, l, false);
+  if (c->world == 1) {
+    a.out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
+    a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
+    a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
+    a.gate = Hin;
+    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
+  } else {
+    a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
+    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
+  }
+  return RGCN_OK;
+}
+
+static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
+  if (l != c->bwd_layer || l < 1) RGCN_FAIL(c, RGCN_ERR_STATE, "backward layers must run L..1 in order");
+  float* out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
+  DropSpec d2 = make_drop(c, l - 1, l - 1 >= 1);
+  float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
+  if (c->world > 1) {
+    CombineArgs a;
+    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr;
+    a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = 0; a.row_hi = c->V;
+    a.drop = make_drop(c, l, false);
+    a.drop2 = d2;
+    RGCN_TRY(combine(c, "combine_bwd_finish", a, 4.0 * c->d * (out2 ? 4.0 : 3.0) * c->V));
+  }
+  c->bwd_D = out;
+  c->bwd_dS = out2 ? out2 : out;
+  c->bwd_layer = l - 1;
+  return RGCN_OK;
+}
+
+static rgcn_status bwd_end(rgcn_ctx* c) {
+  if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
+  // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
+  return column_sum(c, c->g_emb, c->gb_emb, c->V, c->d);
+}
+
+static rgcn_status forward_all(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks) {
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
+  RGCN_TRY(fwd_begin(c, train, seed, masks));
+  for (int l = 1; l <= c->L; ++l) {
+    RGCN_TRY(fwd_layer_partial(c, l));
+    if (c->world > 1) RGCN_TRY(comm_allreduce(c, c->exch, (int64_t)c->V * c->d));
+    RGCN_TRY(fwd_layer_finish(c, l));
+  }
+  return RGCN_OK;
+}
+
+static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev) {
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
+  RGCN_TRY(bwd_begin(c, dcodes_dev));
+  for (int l = c->L; l >= 1; --l) {
+    RGCN_TRY(bwd_layer_partial(c, l));
+    if (c->world > 1) {
+      RGCN_TRY(comm_allreduce(c, c->exch, (int64_t)c->V * c->d));
+      RGCN_TRY(comm_allreduce(c, c->layers[l].gwself, (int64_t)c->d * c->d));
+    }
+    RGCN_TRY(bwd_layer_finish(c, l));
+  }
+  return bwd_end(c);
+}
+
+}  // namespace rgcn
+
+using namespace rgcn;
+
+// ================================================================= C ABI
+#define RGCN_NEED(c)                \
+  do {                              \
+    if (!(c)) return RGCN_ERR_INVALID; \
+    (void)hipSetDevice((c)->cfg.device); \
+  } while (0)
+
+extern "C" {
+
+int32_t rgcn_abi_version(void) { return RGCN_ABI_VERSION; }
+
+rgcn_status rgcn_create(const rgcn_config* cfg, rgcn_ctx** out) {
+  if (!cfg || !out) { set_global_error("rgcn_create: NULL argument"); return RGCN_ERR_INVALID; }
+  *out = nullptr;
+  rgcn_ctx* c = new (std::nothrow) rgcn_ctx();
+  if (!c) { set_global_error("out of host memory"); return RGCN_ERR_NOMEM; }
+  c->cfg = *cfg;
+  rgcn_status s = create_impl(c);
+  if (s != RGCN_OK) {
+    set_global_error(c->err);
+    free_all(c);
+    return s;
+  }
+  *out = c;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_destroy(rgcn_ctx* ctx) {
+  if (!ctx) return RGCN_OK;
+  free_all(ctx);
+  return RGCN_OK;
+}
+
+const char* rgcn_last_error(const rgcn_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  copy = g_err;
+  return copy.c_str();
+}
+
+rgcn_status rgcn_sync(rgcn_ctx* c) {
+  RGCN_NEED(c);
+  return check_dev_flag(c);
+}
+
+int32_t rgcn_param_count(const rgcn_ctx* c) { return c ? (int32_t)c->params.size() : 0; }
+
+rgcn_status rgcn_param_info(const rgcn_ctx* c, int32_t index, char* name, int32_t name_cap,
+                            int64_t shape[4], int32_t* ndim) {
+  if (!c || index < 0 || index >= (int32_t)c->params.size()) return RGCN_ERR_INVALID;
+  const Param& p = c->params[index];
+  if (name && name_cap > 0) {
+    strncpy(name, p.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  if (ndim) *ndim = p.ndim;
+  return RGCN_OK;
+}
+
+static rgcn_status param_check(rgcn_ctx* c, int32_t index, const void* host, int64_t count) {
+  if (index < 0 || index >= (int32_t)c->params.size()) RGCN_FAIL(c, RGCN_ERR_INVALID, "parameter index out of range");
+  if (!host) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL host pointer");
+  if (count != c->params[index].count)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "element count does not match parameter " + c->params[index].name);
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_set_param(rgcn_ctx* c, int32_t index, const float* host, int64_t count) {
+  RGCN_NEED(c);
+  RGCN_TRY(param_check(c, index, host, count));
+  return param_upload(c, c->params[index], c->params[index].val, host);
+}
+rgcn_status rgcn_get_param(rgcn_ctx* c, int32_t index, float* host, int64_t count) {
+  RGCN_NEED(c);
+  RGCN_TRY(param_check(c, index, host, count));
+  return param_download(c, c->params[index], c->params[index].val, host);
+}
+rgcn_status rgcn_get_grad(rgcn_ctx* c, int32_t index, float* host, int64_t count) {
+  RGCN_NEED(c);
+  RGCN_TRY(param_check(c, index, host, count));
+  RGCN_TRY(check_dev_flag(c));
+  return param_download(c, c->params[index], c->params[index].grad, host);
+}
+
+rgcn_status rgcn_set_graph(rgcn_ctx* c, const int32_t* tri, int64_t E) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (E > 0 && !tri) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
+  for (int64_t e = 0; e < E; ++e) {
+    const int32_t s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
+    if (s < 0 || s >= c->V || o < 0 || o >= c->V || r < 0 || r >= c->R)
+      RGCN_FAIL(c, RGCN_ERR_INVALID, "graph_edges row " + std::to_string(e) + " has an id out of range");
+  }
+  if (E > 0) RGCN_TRY(to_dev(c, c->g.triples, tri, sizeof(int32_t) * 3 * (size_t)E));
+  return graph_build(c, c->g.triples, E);
+}
+
+rgcn_status rgcn_set_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (E > 0 && !tri_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
+  return graph_build(c, tri_dev, E);
+}
+
+rgcn_status rgcn_forward(rgcn_ctx* c, int32_t train, uint64_t seed, const uint8_t* masks) {
+  RGCN_NEED(c);
+  return forward_all(c, train, seed, masks);
+}
+
+rgcn_status rgcn_get_activation(rgcn_ctx* c, int32_t layer, float* host, int64_t count) {
+  RGCN_NEED(c);
+  if (layer < 0 || layer > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
+  if (!host || count != (int64_t)c->V * c->d) RGCN_FAIL(c, RGCN_ERR_INVALID, "need a [V,d] host buffer");
+  if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "no completed forward pass");
+  RGCN_TRY(check_dev_flag(c));
+  return to_host(c, host, c->H[layer], sizeof(float) * (size_t)count);
+}
+rgcn_status rgcn_get_codes(rgcn_ctx* c, float* host, int64_t count) {
+  if (!c) return RGCN_ERR_INVALID;
+  return rgcn_get_activation(c, c->L, host, count);
+}
+const float* rgcn_codes_device(rgcn_ctx* c) { return c ? c->H[c->L] : nullptr; }
+
+rgcn_status rgcn_get_dropout_mask(rgcn_ctx* c, int32_t layer, uint8_t* host, int64_t count) {
+  RGCN_NEED(c);
+  if (layer < 1 || layer > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
+  if (!host || count != (int64_t)c->V * c->d) RGCN_FAIL(c, RGCN_ERR_INVALID, "need a [V,d] host buffer");
+  DropSpec ds = make_drop(c, layer, true);
+  uint8_t* tmp = reinterpret_cast<uint8_t*>(c->stage);
+  RGCN_TRY(materialize_mask(c, ds, tmp, count));
+  return to_host(c, host, tmp, (size_t)count);
+}
+
+rgcn_status rgcn_backward_device(rgcn_ctx* c, const float* dcodes_dev) {
+  RGCN_NEED(c);
+  return backward_all(c, dcodes_dev);
+}
+rgcn_status rgcn_backward(rgcn_ctx* c, const float* dcodes_host, int64_t count) {
+  RGCN_NEED(c);
+  if (!dcodes_host || count != (int64_t)c->V * c->d) RGCN_FAIL(c, RGCN_ERR_INVALID, "dcodes must be [V,d]");
+  if (!c->dcodes_own) RGCN_TRY(dmalloc(c, &c->dcodes_own, (size_t)count, false));
+  RGCN_TRY(to_dev(c, c->dcodes_own, dcodes_host, sizeof(float) * (size_t)count));
+  return backward_all(c, c->dcodes_own);
+}
+
+rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int32_t train,
+                             uint64_t seed, const float* dcodes_dev) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  RGCN_TRY(graph_build(c, tri_dev, E));
+  RGCN_TRY(forward_all(c, train, seed, nullptr));
+  return backward_all(c, dcodes_dev);
+}
+
+rgcn_status rgcn_set_relation_owner(rgcn_ctx* c, const int32_t* owner, int32_t count) {
+  RGCN_NEED(c);
+  if (!owner || count != c->R) RGCN_FAIL(c, RGCN_ERR_INVALID, "owner must have RelationCount entries");
+  for (int r = 0; r < count; ++r)
+    if (owner[r] < 0 || owner[r] >= c->world) RGCN_FAIL(c, RGCN_ERR_INVALID, "owner[r] outside [0, world)");
+  c->g.ready = false;
+  c->fwd_done = false;
+  return to_dev(c, c->g.owner, owner, sizeof(int32_t) * (size_t)count);
+}
+
+rgcn_status rgcn_comm_unique_id(uint8_t id[128]) {
+  if (!id) return RGCN_ERR_INVALID;
+  return comm_unique_id(id);
+}
+rgcn_status rgcn_comm_init(rgcn_ctx* c, const uint8_t id[128]) {
+  RGCN_NEED(c);
+  if (!id) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL id");
+  return comm_init(c, id);
+}
+rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* c, float* dev, int64_t count) {
+  RGCN_NEED(c);
+  return comm_allreduce(c, dev, count);
+}
+
+rgcn_status rgcn_forward_begin(rgcn_ctx* c, int32_t train, uint64_t seed, const uint8_t* masks) {
+  RGCN_NEED(c);
+  return fwd_begin(c, train, seed, masks);
+}
+rgcn_status rgcn_forward_layer_partial(rgcn_ctx* c, int32_t l) { RGCN_NEED(c); return fwd_layer_partial(c, l); }
+rgcn_status rgcn_forward_layer_finish(rgcn_ctx* c, int32_t l) { RGCN_NEED(c); return fwd_layer_finish(c, l); }
+rgcn_status rgcn_backward_begin(rgcn_ctx* c, const float* dcodes_dev) { RGCN_NEED(c); return bwd_begin(c, dcodes_dev); }
+rgcn_status rgcn_backward_layer_partial(rgcn_ctx* c, int32_t l) { RGCN_NEED(c); return bwd_layer_partial(c, l); }
+rgcn_status rgcn_backward_layer_finish(rgcn_ctx* c, int32_t l) { RGCN_NEED(c); return bwd_layer_finish(c, l); }
+rgcn_status rgcn_backward_end(rgcn_ctx* c) { RGCN_NEED(c); return bwd_end(c); }
+
+static rgcn_status buffer_of(rgcn_ctx* c, int32_t which, void** p, int64_t* bytes) {
+  const int64_t Vd = (int64_t)c->V * c->d * 4;
+  switch (which) {
+    case RGCN_BUF_EXCHANGE:
+      if (!c->exch) RGCN_FAIL(c, RGCN_ERR_STATE, "no exchange buffer on a world == 1 context");
+      *p = c->exch; *bytes = Vd; return RGCN_OK;
+    case RGCN_BUF_SELF: *p = c->self_buf; *bytes = Vd; return RGCN_OK;
+    case RGCN_BUF_DSELF_EXCHANGE: {
+      int l = c->bwd_layer;
+      if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_STATE, "no backward layer in flight");
+      *p = c->layers[l].gwself; *bytes = (int64_t)c->d * c->d * 4; return RGCN_OK;
+    }
+    case RGCN_BUF_INDEG: *p = c->g.indeg; *bytes = (int64_t)c->V * 4; return RGCN_OK;
+    case RGCN_BUF_OUTDEG: *p = c->g.outdeg; *bytes = (int64_t)c->V * 4; return RGCN_OK;
+    case RGCN_BUF_ROWPTR: *p = c->g.row_ptr; *bytes = (int64_t)(c->V + 1) * 4; return RGCN_OK;
+    default: RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown buffer id");
+  }
+}
+rgcn_status rgcn_read_buffer(rgcn_ctx* c, int32_t which, void* host, int64_t bytes) {
+  RGCN_NEED(c);
+  void* p; int64_t n;
+  RGCN_TRY(buffer_of(c, which, &p, &n));
+  if (!host || bytes != n) RGCN_FAIL(c, RGCN_ERR_INVALID, "buffer size mismatch");
+  return to_host(c, host, p, (size_t)n);
+}
+rgcn_status rgcn_write_buffer(rgcn_ctx* c, int32_t which, const void* host, int64_t bytes) {
+  RGCN_NEED(c);
+  void* p; int64_t n;
+  RGCN_TRY(buffer_of(c, which, &p, &n));
+  if (!host || bytes != n) RGCN_FAIL(c, RGCN_ERR_INVALID, "buffer size mismatch");
+  if (which != RGCN_BUF_EXCHANGE && which != RGCN_BUF_DSELF_EXCHANGE)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "only the exchange buffers are writable");
+  return to_dev(c, p, host, (size_t)n);
+}
+
+rgcn_status rgcn_device_alloc(rgcn_ctx* c, int64_t bytes, void** dev) {
+  RGCN_NEED(c);
+  if (!dev || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  RGCN_HIP(c, hipMalloc(dev, (size_t)(bytes ? bytes : 1)));
+  return RGCN_OK;
+}
+rgcn_status rgcn_device_free(rgcn_ctx* c, void* dev) {
+  RGCN_NEED(c);
+  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  if (dev) RGCN_HIP(c, hipFree(dev));
+  return RGCN_OK;
+}
+rgcn_status rgcn_copy_to_device(rgcn_ctx* c, void* dev, const void* host, int64_t bytes) {
+  RGCN_NEED(c);
+  if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  return to_dev(c, dev, host, (size_t)bytes);
+}
+rgcn_status rgcn_copy_to_host(rgcn_ctx* c, void* host, const void* dev, int64_t bytes) {
+  RGCN_NEED(c);
+  if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  return to_host(c, host, dev, (size_t)bytes);
+}
+
+rgcn_status rgcn_timer_start(rgcn_ctx* c) {
+  RGCN_NEED(c);
+  RGCN_HIP(c, hipEventRecord(c->t0, c->stream));
+  return RGCN_OK;
+}
+rgcn_status rgcn_timer_stop(rgcn_ctx* c, float* ms) {
+  RGCN_NEED(c);
+  if (!ms) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
+  RGCN_HIP(c, hipEventRecord(c->t1, c->stream));
+  RGCN_HIP(c, hipEventSynchronize(c->t1));
+  RGCN_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_profile_enable(rgcn_ctx* c, int32_t on) {
+  RGCN_NEED(c);
+  if (!on && c->prof_on) RGCN_TRY(profile_collect(c));
+  c->prof_on = on != 0;
+  return RGCN_OK;
+}
+rgcn_status rgcn_profile_reset(rgcn_ctx* c) {
+  RGCN_NEED(c);
+  RGCN_TRY(profile_collect(c));
+  c->prof_agg.clear();
+  return RGCN_OK;
+}
+int32_t rgcn_profile_count(rgcn_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->cfg.device);
+  if (profile_collect(c) != RGCN_OK) return 0;
+  return (int32_t)c->prof_agg.size();
+}
+rgcn_status rgcn_profile_get(rgcn_ctx* c, int32_t i, char* name, int32_t name_cap, int64_t* calls,
+                             double* total_ms, double* alg_bytes, double* alg_flops) {
+  RGCN_NEED(c);
+  if (i < 0 || i >= (int32_t)c->prof_agg.size()) RGCN_FAIL(c, RGCN_ERR_INVALID, "profile index out of range");
+  const ProfAgg& a = c->prof_agg[i];
+  if (name && name_cap > 0) {
+    strncpy(name, a.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (calls) *calls = a.calls;
+  if (total_ms) *total_ms = a.ms;
+  if (alg_bytes) *alg_bytes = a.bytes;
+  if (alg_flops) *alg_flops = a.flops;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
+                            int32_t split_k, const float* a_host, const float* b_host, float* c_host) {
+  RGCN_NEED(c);
+  if (M <= 0 || N <= 0 || K <= 0 || !a_host || !b_host || !c_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  if (ta && tb) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "TT form not instantiated");
+  float *A = nullptr, *B = nullptr, *C = nullptr;
+  rgcn_status s = RGCN_OK;
+  do {
+    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
+    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
+    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
+    int sk = split_k > 0 ? split_k : auto_split_k(M, N, K);
+    if ((size_t)sk * M * N > c->slab_floats) sk = 1;
+    // trans_a: A given as [K,M] (row-contiguous operand); trans_b: B given as [N,K] (k-contiguous)
+    s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
+    if (s != RGCN_OK) break;
+    s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N);
+  } while (0);
+  if (A) (void)hipFree(A);
+  if (B) (void)hipFree(B);
+  if (C) (void)hipFree(C);
+  return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// Internal declarations shared by the translation units of librgcn.so.
+// Nothing here is part of the C ABI (include/rgcn.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rgcn.h"
+
+namespace rgcn {
+
+// ---------------------------------------------------------------- error plumbing
+void set_global_error(const std::string& s);
+
+#define RGCN_HIP(ctx, expr)                                                                      \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +       \
+                   std::to_string(__LINE__) + ")";                                               \
+      return RGCN_ERR_HIP;                                                                       \
+    }                                                                                            \
+  } while (0)
+
+#define RGCN_TRY(expr)                       \
+  do {                                       \
+    rgcn_status _s = (expr);                 \
+    if (_s != RGCN_OK) return _s;            \
+  } while (0)
+
+#define RGCN_FAIL(ctx, code, msg)            \
+  do {                                       \
+    (ctx)->err = (msg);                      \
+    return (code);                           \
+  } while (0)
+
+// ---------------------------------------------------------------- dropout generator
+// Counter-based Bernoulli(keep) draw: nothing is stored, forward and backward re-derive the same
+// bit from (seed, layer, flat element index).  splitmix64 finaliser; top 24 bits compared with
+// keep_prob * 2^24.  Statistically equivalent to tf.nn.dropout's floor(keep + U[0,1))
+// (message_gcn.py:64); the exact TF Philox stream is not reproducible (parity tests inject masks).
+__host__ __device__ inline uint32_t drop_bits(uint64_t seed, uint32_t layer, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + ((uint64_t)layer << 44) + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= (z >> 31);
+  return (uint32_t)(z >> 40);
+}
+
+enum DropMode { DROP_NONE = 0, DROP_RNG = 1, DROP_MASK = 2 };
+
+struct DropSpec {
+  int32_t mode;         // DropMode
+  uint32_t layer;       // 1..L
+  uint32_t thresh;      // keep iff drop_bits < thresh
+  float inv_keep;       // 1 / keep_prob
+  uint64_t seed;
+  const uint8_t* mask;  // [V,d] 0/1 for this layer (DROP_MASK)
+};
+
+// ---------------------------------------------------------------- profiling records
+struct ProfRec {
+  const char* name;
+  hipEvent_t e0, e1;
+  double bytes, flops;
+};
+struct ProfAgg {
+  std::string name;
+  int64_t calls;
+  double ms, bytes, flops;
+};
+
+// ---------------------------------------------------------------- parameters
+enum ParamLayout {
+  LAYOUT_PLAIN = 0,        // device layout == host layout
+  LAYOUT_BLOCK_T = 1,      // host [R][nb][sd*sd]  <-> device [R][sd*sd][nb]
+  LAYOUT_BASIS_T = 2       // host [d][B][d]       <-> device [B][d][d]
+};
+
+struct Param {
+  std::string name;
+  int32_t ndim;
+  int64_t shape[4];
+  int64_t count;
+  float* val;    // device (view into a layer allocation for W_f/W_b)
+  float* grad;   // device
+  int32_t layout;
+};
+
+struct LayerBufs {
+  // BLOCK: wrel = [2R][sd*sd][nb] (first R = W_forward, last R = W_backward), same for grel.
+  // BASIS: wrel = [2][B][d][d]  (GEMM operand [2B*d, d]); coef = [2R][B] (first R = C_forward).
+  float* wrel = nullptr;
+  float* grel = nullptr;
+  float* coef = nullptr;
+  float* gcoef = nullptr;
+  float* wself = nullptr;   // [d,d]
+  float* gwself = nullptr;
+  float* bias = nullptr;    // [d], unused by the math
+  float* gbias = nullptr;
+};
+
+struct GraphBufs {
+  int32_t* triples = nullptr;   // [maxE,3] (only when the host variant of set_graph is used)
+  const int32_t* cur = nullptr; // triples of the current graph (ours or the caller's)
+  int64_t E = 0;
+  int32_t* indeg = nullptr;     // [V]
+  int32_t* outdeg = nullptr;    // [V]
+  int32_t* cnt = nullptr;       // [V]   owned incidences per vertex
+  int32_t* relcnt = nullptr;    // [2R]  owned messages per directed relation
+  int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, cnt, relcnt)
+  size_t counters_bytes = 0;
+  int32_t* row_ptr = nullptr;   // [V+1]
+  int32_t* rel_ptr = nullptr;   // [2R+1]
+  int32_t* chunk_ptr = nullptr; // [2R+1]
+  int32_t* cum_in = nullptr;    // [V+1]  (tf_as_executed)
+  int32_t* cum_out = nullptr;   // [V+1]
+  uint32_t *keyv = nullptr, *keyv_s = nullptr, *keyr = nullptr, *keyr_s = nullptr;  // [2maxE]
+  int32_t *valv = nullptr, *permv = nullptr, *valr = nullptr, *permr = nullptr;      // [2maxE]
+  int32_t* pos = nullptr;       // [2maxE] incidence -> CSR slot
+  // relation-sorted message list (SoA, [2maxE] each)
+  int32_t *m_src = nullptr, *m_dst = nullptr, *m_dslot = nullptr, *m_sslot = nullptr;
+  float* m_norm = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int32_t* owner = nullptr;     // [R]
+  int32_t* errflag = nullptr;   // device int: nonzero = bad id seen
+  bool ready = false;
+};
+
+}  // namespace rgcn
+
+struct rgcn_ctx {
+  rgcn_config cfg;
+  int V = 0, R = 0, d = 0, L = 0, nb = 0, sd = 0, kind = 0, B = 0;
+  int rank = 0, world = 1;
+  int row_lo = 0, row_hi = 0;   // self-loop row shard of this rank
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  std::vector<rgcn::Param> params;
+  std::vector<rgcn::LayerBufs> layers;   // index 1..L (0 unused)
+  float *w_emb = nullptr, *g_emb = nullptr, *b_emb = nullptr, *gb_emb = nullptr;
+
+  std::vector<float*> H;                 // H[0..L], [V,d] each
+  float* self_buf = nullptr;             // S / G : [V,d]
+  float* exch = nullptr;                 // exchange buffer [V,d] (world > 1)
+  float* dbuf[2] = {nullptr, nullptr};   // D_l ping-pong
+  float* dsbuf[2] = {nullptr, nullptr};  // dS_l ping-pong
+  float* msgbuf = nullptr;               // Y / Z : [2*maxE, d]  (BLOCK)   or Z [V, 2B*d] (BASIS)
+  float* msgbuf2 = nullptr;              // BASIS: dZ [V, 2B*d]
+  float* slab = nullptr;                 // split-K / dW partial slabs
+  size_t slab_floats = 0;
+  float* stage = nullptr;                // host<->device staging for layout conversion
+  size_t stage_floats = 0;
+  uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
+  float* colsum_part = nullptr;
+
+  rgcn::GraphBufs g;
+  int chunk = 96;                        // messages per relation chunk
+  int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
+
+  // forward/backward state
+  bool fwd_done = false;
+  int fwd_train = 0;
+  uint64_t seed = 0;
+  bool explicit_masks = false;
+  const float* bwd_D = nullptr;          // D_l of the backward layer in flight
+  const float* bwd_dS = nullptr;         // dS_l = D_l * dropout_l
+  int bwd_layer = 0;                     // next layer the backward pass will process (L..1, 0 = done)
+  float* dcodes_own = nullptr;           // [V,d] staging for the host variant of backward
+
+  // comm
+  void* comm = nullptr;                  // ncclComm_t
+  // profiling
+  bool prof_on = false;
+  std::vector<rgcn::ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<rgcn::ProfAgg> prof_agg;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace rgcn {
+
+// Brackets a launch with events when profiling is on.
+struct ProfScope {
+  rgcn_ctx* c;
+  int idx;
+  ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops);
+  ~ProfScope();
+};
+
+// ---- graph_prep.hip
+rgcn_status graph_alloc(rgcn_ctx* c);
+void graph_free(rgcn_ctx* c);
+rgcn_status graph_build(rgcn_ctx* c, const int32_t* triples_dev, int64_t E);
+
+// ---- gemm_f32.hip
+// C[M,N] (ldc) = A(m,k) . B(k,n).  a_kc: A stored [m][k] (k contiguous, lda) else [k][m];
+// b_kc: B stored [n][k] (k contiguous, ldb) else [k][n].  split_k > 1 writes partial slabs to
+// `slab` ([split_k][M][N]) and reduces them into C deterministically.
+rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
+                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     int split_k);
+
+// ---- block_msgs.hip
+rgcn_status block_geometry(rgcn_ctx* c);
+rgcn_status block_msg_forward(rgcn_ctx* c, int layer, const float* Hin, float* Ybuf);
+rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const float* D, float* Zbuf);
+rgcn_status block_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst, int R);
+rgcn_status block_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev, int R);
+
+// ---- basis.hip
+rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z);
+rgcn_status basis_backward_sparse(rgcn_ctx* c, int layer, const float* Hin, const float* dZ, float* Zt);
+rgcn_status basis_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst);
+rgcn_status basis_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev);
+
+// ---- elementwise.hip
+struct CombineArgs {
+  float* out;            // primary output [V,d]
+  float* out2;           // optional: out * dropout(drop2)
+  const float* base;     // optional [V,d] (valid for rows in [row_lo,row_hi))
+  const float* msg;      // optional message rows [slots,d]; summed per CSR row
+  const int32_t* row_ptr;
+  const float* gate;     // optional: result *= (gate > 0)
+  int32_t V, d;
+  int32_t relu;
+  int32_t row_lo, row_hi;
+  DropSpec drop;         // applied to base
+  DropSpec drop2;        // applied to out2
+};
+rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
+rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
+rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds);
+rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols);
+rgcn_status relu_copy(rgcn_ctx* c, const float* in, float* out, int64_t n, int relu);
+rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, int64_t n);
+
+DropSpec make_drop(const rgcn_ctx* c, int layer, bool active);
+
+// ---- comm.cpp (RCCL via dlopen)
+rgcn_status comm_unique_id(uint8_t id[128]);
+rgcn_status comm_init(rgcn_ctx* c, const uint8_t id[128]);
+rgcn_status comm_allreduce(rgcn_ctx* c, float* buf, int64_t count);
+void comm_destroy(rgcn_ctx* c);
+
+}  // namespace rgcn

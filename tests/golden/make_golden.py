@@ -1,0 +1,83 @@
+"""Generate the committed fixtures under tests/golden/.
+
+    python tests/golden/make_golden.py          (needs /root/reference for the real graphs)
+
+graphs.npz   real graph structure read from the reference's data files with the reference's own
+             file formats (code/common/io.py:5-39): Toy train (43 triples, complete) and the
+             FB15k-237 minibatch of SURVEY.md 8d config 2 "graph A" (30,000 of the 38,001 valid+test
+             triples, seed 0, no replacement; then a random 15,000 of them = GraphSplitSize 0.5).
+expected.npz fingerprints (l2 norm, sum, 256 sampled entries) of the ORACLE's outputs on the cases
+             in tests/helpers.py:GOLDEN_CASES.  The reference ships no golden vectors and TF 1.4
+             cannot run here ("parity unpinned"), so these pin the oracle against regressions and
+             give the GPU tests a reference-file-free target; they are NOT reference outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import oracle  # noqa: E402
+import helpers  # noqa: E402
+
+REF = "/root/reference/data"
+
+
+def read_dictionary(path):
+    d = {}
+    for line in open(path):
+        k, v = line.rstrip("\n").split("\t")
+        d[v] = int(k)
+    return d
+
+
+def read_triples(path, ent, rel):
+    out = []
+    for line in open(path):
+        s, r, o = line.rstrip("\n").split("\t")
+        out.append([ent[s], rel[r], ent[o]])
+    return np.array(out, dtype=np.int32)
+
+
+def make_graphs():
+    ent = read_dictionary(REF + "/Toy/entities.dict")
+    rel = read_dictionary(REF + "/Toy/relations.dict")
+    toy = read_triples(REF + "/Toy/train.txt", ent, rel)
+    assert toy.shape == (43, 3) and len(ent) == 16 and len(rel) == 9
+    ent = read_dictionary(REF + "/FB-Toutanova/entities.dict")
+    rel = read_dictionary(REF + "/FB-Toutanova/relations.dict")
+    fb = np.concatenate([read_triples(REF + "/FB-Toutanova/valid.txt", ent, rel),
+                         read_triples(REF + "/FB-Toutanova/test.txt", ent, rel)], axis=0)
+    assert fb.shape == (38001, 3) and len(ent) == 14541 and len(rel) == 237
+    rng = np.random.default_rng(0)
+    batch = rng.choice(fb.shape[0], size=30000, replace=False)
+    split = rng.choice(batch, size=15000, replace=False)
+    np.savez_compressed(os.path.join(HERE, "graphs.npz"), toy_train=toy, fb237_minibatch=fb[split],
+                        fb237_valid_test=fb)
+
+
+def make_expected():
+    out = {}
+    for name in helpers.GOLDEN_CASES:
+        c = helpers.golden_inputs(name)
+        for norm in ("intended", "tf_as_executed"):
+            acts, grads = oracle.encoder_step(c["params"], c["triples"], c["V"], c["L"], c["kind"],
+                                              c["dcodes"], keep_prob=0.8, dropout_masks=c["masks"],
+                                              norm_mode=norm)
+            tensors = {"codes": acts[-1], "H0": acts[0]}
+            tensors.update({"grad_" + k: v for k, v in grads.items()})
+            for tname, t in tensors.items():
+                pr = helpers.probe(t)
+                for field, v in pr.items():
+                    out["%s/%s/%s/%s" % (name, norm, tname, field)] = v
+        print("done", name)
+    np.savez_compressed(os.path.join(HERE, "expected.npz"), **out)
+
+
+if __name__ == "__main__":
+    if os.path.isdir(REF):
+        make_graphs()
+    make_expected()

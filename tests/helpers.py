@@ -16,3 +16,65 @@ def make_case(V, R, d, L, kind, nb, E, seed=0, train=True, keep=0.8, self_edges=
     masks = [(rng.rand(V, d) < keep).astype(np.uint8) for _ in range(L)] if train else None
     dcodes = (rng.randn(V, d) * 1e-1).astype(np.float32)
     return params, triples, masks, dcodes
+
+
+# ----------------------------------------------------------------------------- golden cases
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> (graph fixture, V, R, d, L, kind, nb, seed).  Shapes follow BASELINE.json's configs:
+# config 1 (Toy, gcn_basis.exp keys, 1 layer), config 2 (FB15k-237 gcn_block), config 3 (gcn_basis B=2).
+GOLDEN_CASES = {
+    "toy_basis_L1": ("toy_train", 16, 9, 500, 1, "basis", 5, 11),
+    "toy_block_L2": ("toy_train", 16, 9, 500, 2, "block", 100, 12),
+    "toy_block_small": ("toy_train", 16, 9, 10, 2, "block", 2, 13),
+    "fb237_block_L2": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 21),
+    "fb237_basis_B2_L2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 22),
+}
+
+
+def load_graph(name):
+    with np.load(os.path.join(GOLDEN_DIR, "graphs.npz")) as z:
+        return z[name].astype(np.int32)
+
+
+def golden_inputs(name):
+    """Deterministic inputs of a golden case (weights are regenerated from the seed, not stored)."""
+    graph, V, R, d, L, kind, nb, seed = GOLDEN_CASES[name]
+    rng = np.random.RandomState(seed)
+    params = oracle.init_params(V, R, d, L, kind, nb, rng=rng)
+    params["b_emb"] = (rng.randn(d) * 0.01).astype(np.float32)
+    masks = [(rng.rand(V, d) < 0.8).astype(np.uint8) for _ in range(L)]
+    dcodes = (rng.randn(V, d) * 1e-2).astype(np.float32)
+    return dict(V=V, R=R, d=d, L=L, kind=kind, nb=nb, params=params, masks=masks, dcodes=dcodes,
+                triples=load_graph(graph))
+
+
+def probe(arr, n=256, seed=0):
+    """Compact fingerprint of a tensor: l2 norm, sum and n sampled entries (fixed positions)."""
+    a = np.asarray(arr, dtype=np.float32).ravel()
+    idx = np.random.RandomState(seed).randint(0, a.size, size=min(n, a.size))
+    return dict(l2=np.float64(np.sqrt(np.sum(a.astype(np.float64) ** 2))),
+                sum=np.float64(a.astype(np.float64).sum()), idx=idx.astype(np.int64), val=a[idx].copy())
+
+
+def check_probe(arr, pr, rel=2e-4, name=""):
+    a = np.asarray(arr, dtype=np.float32).ravel()
+    scale = max(float(np.abs(pr["val"]).max()), 1e-12)
+    err = float(np.abs(a[pr["idx"]] - pr["val"]).max())
+    assert err <= rel * scale + 1e-7, "%s: sampled entries differ: err %.3e scale %.3e" % (name, err, scale)
+    l2 = float(np.sqrt(np.sum(a.astype(np.float64) ** 2)))
+    assert abs(l2 - float(pr["l2"])) <= rel * max(float(pr["l2"]), 1e-12) + 1e-7, "%s: l2 norm differs" % name
+
+
+def assert_close(got, ref, rel=2e-4, abs_tol=1e-7, name=""):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    if ref.size == 0:
+        return
+    assert np.isfinite(got).all(), "%s: non-finite values" % name
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max())
+    assert err <= rel * scale + abs_tol, "%s: max err %.3e vs scale %.3e (rel %.1e)" % (name, err, scale, rel)

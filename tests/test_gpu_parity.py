@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  Tolerance: forward activations within 1e-4 absolute (BASELINE.json north_star,
+fp32) -- enforced as max|err| <= 1e-4; gradients within 2e-4 of the tensor's max magnitude (fp32
+summation order differs from the oracle's; SURVEY.md 8c "TF numerics to mirror").
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import helpers
+from helpers import assert_close, make_case
+
+pytestmark = pytest.mark.gpu
+
+FWD_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+def run_engine(native, V, R, d, L, kind, nb, params, triples, masks, dcodes, norm="intended", train=True,
+               keep=0.8, seed=0):
+    eng = native.Engine(V, R, d, L, kind, nb, keep_prob=keep, norm_mode=norm, max_edges=max(len(triples), 1))
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=train, seed=seed, masks=masks if train else None)
+        acts = [eng.activation(l) for l in range(L + 1)]
+        eng.backward(dcodes)
+        grads = eng.get_grads()
+        return acts, grads
+    finally:
+        eng.close()
+
+
+def compare(acts, grads, oacts, ograds, tag=""):
+    for l, (a, b) in enumerate(zip(acts, oacts)):
+        assert a.shape == b.shape
+        assert np.isfinite(a).all(), "%s H%d non-finite" % (tag, l)
+        err = float(np.abs(a - b).max()) if a.size else 0.0
+        assert err <= FWD_ATOL, "%s H%d: max abs err %.3e" % (tag, l, err)
+    for name, g in grads.items():
+        assert_close(g, ograds[name], rel=2e-4, name="%s grad %s" % (tag, name))
+
+
+# ------------------------------------------------------------------ dense contraction (fp32 MFMA GEMM)
+GEMM_SHAPES = [
+    (1, 1, 1), (33, 17, 5), (128, 128, 16), (129, 130, 33), (257, 500, 500), (1000, 500, 500),
+    (64, 64, 4), (500, 500, 1000), (300, 77, 129),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("form", ["NN", "NT", "TN"])
+def test_gemm_forms(native, M, N, K, form):
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rng.randn(M, K).astype(np.float32)
+    B = rng.randn(K, N).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    eng = native.Engine(16, 2, 8, 1, "block", 2, max_edges=4)
+    try:
+        if form == "NN":
+            got = eng.debug_gemm(A, B)
+        elif form == "NT":
+            got = eng.debug_gemm(A, np.ascontiguousarray(B.T), trans_b=True)
+        else:
+            got = eng.debug_gemm(np.ascontiguousarray(A.T), B, trans_a=True)
+            got2 = eng.debug_gemm(np.ascontiguousarray(A.T), B, trans_a=True, split_k=3)
+            assert_close(got2, ref, rel=1e-5, name="TN split 3")
+    finally:
+        eng.close()
+    # asymmetric random operands: a swapped row/col mapping cannot pass
+    assert_close(got, ref, rel=1e-5, name=form)
+
+
+# ------------------------------------------------------------------ graph preparation
+def test_graph_prep_degrees_and_csr(native):
+    rng = np.random.RandomState(0)
+    V, R, E = 97, 5, 400
+    triples = np.stack([rng.randint(0, V, E), rng.randint(0, R, E), rng.randint(0, V, E)], 1).astype(np.int32)
+    triples[:10, 2] = triples[:10, 0]          # self edges
+    triples[10:20] = triples[0]                # duplicates
+    eng = native.Engine(V, R, 8, 1, "block", 2, max_edges=E)
+    try:
+        eng.set_graph(triples)
+        eng.sync()
+        indeg = eng.read_buffer(native.BUF_INDEG)
+        outdeg = eng.read_buffer(native.BUF_OUTDEG)
+        rowptr = eng.read_buffer(native.BUF_ROWPTR)
+    finally:
+        eng.close()
+    np.testing.assert_array_equal(indeg, np.bincount(triples[:, 2], minlength=V))
+    np.testing.assert_array_equal(outdeg, np.bincount(triples[:, 0], minlength=V))
+    cnt = np.bincount(triples[:, 2], minlength=V) + np.bincount(triples[:, 0], minlength=V)
+    np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(cnt)]))
+
+
+# ------------------------------------------------------------------ encoder forward + backward
+BLOCK_CASES = [
+    # V, R, d, L, nb, E
+    (16, 9, 10, 1, 2, 43),       # Toy-sized, sd = 5
+    (16, 9, 10, 2, 2, 43),
+    (50, 7, 20, 2, 4, 200),      # sd = 5
+    (64, 3, 16, 2, 4, 150),      # sd = 4
+    (30, 3, 8, 3, 8, 60),        # sd = 1, three layers
+    (30, 3, 8, 2, 1, 60),        # nb = 1: one dense 8x8 block
+    (40, 11, 9, 2, 3, 120),      # sd = 3, d % 4 != 0 (scalar paths)
+    (20, 4, 6, 2, 3, 1),         # E = 1
+    (25, 6, 12, 2, 6, 0),        # empty graph
+    (300, 40, 500, 2, 100, 900), # the real block geometry (nb=100, sd=5) at small V
+]
+
+
+@pytest.mark.parametrize("V,R,d,L,nb,E", BLOCK_CASES)
+@pytest.mark.parametrize("norm", ["intended", "tf_as_executed"])
+def test_block_encoder_matches_oracle(native, V, R, d, L, nb, E, norm):
+    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=V + E)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, keep_prob=0.8,
+                                        dropout_masks=masks, norm_mode=norm)
+    acts, grads = run_engine(native, V, R, d, L, "block", nb, params, triples, masks, dcodes, norm=norm)
+    compare(acts, grads, oacts, ograds, tag="block")
+
+
+def test_block_edge_structures(native):
+    """self edges, duplicate edges, a hub row, relations with zero edges, isolated vertices."""
+    V, R, d, L, nb = 60, 12, 20, 2, 4
+    params, _, masks, dcodes = make_case(V, R, d, L, "block", nb, 10, seed=9)
+    rng = np.random.RandomState(4)
+    hub = np.stack([rng.randint(0, 30, 250), rng.randint(0, 3, 250), np.full(250, 7)], 1)   # in-degree 250
+    selfe = np.stack([np.arange(10), np.full(10, 4), np.arange(10)], 1)
+    dup = np.tile(np.array([[1, 2, 3]]), (17, 1))
+    triples = np.concatenate([hub, selfe, dup]).astype(np.int32)    # relations 5..11 unused, vertices 30..59 isolated
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
+    acts, grads = run_engine(native, V, R, d, L, "block", nb, params, triples, masks, dcodes)
+    compare(acts, grads, oacts, ograds, tag="edge-structures")
+    assert not grads["W_f1"][5:].any() and not grads["W_b2"][5:].any()
+
+
+def test_test_mode_has_no_dropout(native):
+    V, R, d, L, nb, E = 40, 5, 20, 2, 4, 100
+    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=2)
+    oacts = oracle.encoder_forward(params, triples, V, L, "block", mode="test")
+    ograds = oracle.encoder_backward(params, triples, V, L, "block", oacts, dcodes, mode="test")
+    acts, grads = run_engine(native, V, R, d, L, "block", nb, params, triples, None, dcodes, train=False)
+    compare(acts, grads, oacts, ograds, tag="test-mode")
+
+
+def test_generated_dropout_is_consistent_and_bernoulli(native):
+    V, R, d, L, nb, E = 200, 5, 40, 2, 8, 500
+    params, triples, _, dcodes = make_case(V, R, d, L, "block", nb, E, seed=6)
+    eng = native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, seed=1234)
+        masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
+        acts = [eng.activation(l) for l in range(L + 1)]
+        eng.backward(dcodes)
+        grads = eng.get_grads()
+        eng.forward(train=True, seed=1235)
+        other = eng.dropout_mask(1)
+    finally:
+        eng.close()
+    for m in masks:
+        assert set(np.unique(m)) <= {0, 1}
+        assert abs(m.mean() - 0.8) < 0.02
+    assert (masks[0] != masks[1]).mean() > 0.2 and (masks[0] != other).mean() > 0.2
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
+    compare(acts, grads, oacts, ograds, tag="rng-dropout")
+
+
+def test_bitwise_deterministic(native):
+    V, R, d, L, nb, E = 120, 9, 20, 2, 4, 700
+    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=8)
+    a1, g1 = run_engine(native, V, R, d, L, "block", nb, params, triples, masks, dcodes)
+    a2, g2 = run_engine(native, V, R, d, L, "block", nb, params, triples, masks, dcodes)
+    for x, y in zip(a1, a2):
+        np.testing.assert_array_equal(x, y)
+    for k in g1:
+        np.testing.assert_array_equal(g1[k], g2[k])
+
+
+def test_param_round_trip_and_layout(native):
+    V, R, d, L, nb = 30, 7, 20, 2, 4
+    params, _, _, _ = make_case(V, R, d, L, "block", nb, 5, seed=3)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=8)
+    try:
+        assert eng.param_names == [n for n in oracle.weight_names("block", L) if n != "W_relation"]
+        eng.set_params(params)
+        for n in eng.param_names:
+            np.testing.assert_array_equal(eng.get_param(n), params[n])
+    finally:
+        eng.close()
+
+
+def test_errors_are_loud(native):
+    eng = native.Engine(10, 3, 8, 1, "block", 2, max_edges=4)
+    try:
+        with pytest.raises(native.RgcnError):
+            eng.forward()                                   # no graph yet
+        with pytest.raises(native.RgcnError):
+            eng.set_graph(np.array([[0, 0, 10]], np.int32))  # vertex id out of range
+        with pytest.raises(native.RgcnError):
+            eng.set_graph(np.array([[0, 3, 1]], np.int32))   # relation id out of range
+        with pytest.raises(native.RgcnError):
+            eng.set_graph(np.zeros((5, 3), np.int32))        # more than max_edges
+        eng.set_graph(np.array([[0, 1, 2]], np.int32))
+        with pytest.raises(native.RgcnError):
+            eng.backward(np.zeros((10, 8), np.float32))      # backward before forward
+        # a bad id in a device-resident graph is flagged at the next sync
+        bad = eng.to_device(np.array([[0, 1, 99]], np.int32))
+        eng.set_graph_device(bad, 1)
+        with pytest.raises(native.RgcnError):
+            eng.sync()
+        bad.free()
+    finally:
+        eng.close()
+    with pytest.raises(native.RgcnError):
+        native.Engine(10, 3, 10, 1, "block", 3, max_edges=4)   # d % nb != 0
+
+
+# ------------------------------------------------------------------ golden fixtures (reference-free)
+@pytest.fixture(scope="module")
+def expected():
+    with np.load(os.path.join(helpers.GOLDEN_DIR, "expected.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def probes_for(expected, case, norm):
+    pre = "%s/%s/" % (case, norm)
+    names = sorted({k[len(pre):].rsplit("/", 1)[0] for k in expected if k.startswith(pre)})
+    return {n: {f: expected[pre + n + "/" + f] for f in ("l2", "sum", "idx", "val")} for n in names}
+
+
+@pytest.mark.parametrize("case", ["toy_block_small", "toy_block_L2", "fb237_block_L2"])
+@pytest.mark.parametrize("norm", ["intended", "tf_as_executed"])
+def test_block_golden(native, expected, case, norm):
+    c = helpers.golden_inputs(case)
+    acts, grads = run_engine(native, c["V"], c["R"], c["d"], c["L"], c["kind"], c["nb"], c["params"],
+                             c["triples"], c["masks"], c["dcodes"], norm=norm)
+    pr = probes_for(expected, case, norm)
+    codes = acts[-1].ravel()
+    err = float(np.abs(codes[pr["codes"]["idx"]] - pr["codes"]["val"]).max())
+    assert err <= FWD_ATOL, "codes: %.3e" % err
+    helpers.check_probe(acts[0], pr["H0"], name="H0")
+    for k, v in grads.items():
+        helpers.check_probe(v, pr["grad_" + k], name=k)
+
+
+def test_fb237_minibatch_full_parity(native):
+    """BASELINE config 2 at full size: FB15k-237 gcn_block, real-structure 15,000-edge minibatch."""
+    c = helpers.golden_inputs("fb237_block_L2")
+    oacts, ograds = oracle.encoder_step(c["params"], c["triples"], c["V"], c["L"], "block", c["dcodes"],
+                                        keep_prob=0.8, dropout_masks=c["masks"])
+    acts, grads = run_engine(native, c["V"], c["R"], c["d"], c["L"], "block", c["nb"], c["params"],
+                             c["triples"], c["masks"], c["dcodes"])
+    compare(acts, grads, oacts, ograds, tag="fb237")
+
+
+def test_full_graph_inference_shape(native):
+    """Full-graph scoring shape (code/model.py:59-81): all 38,001 real FB15k-237 valid+test triples, test mode."""
+    c = helpers.golden_inputs("fb237_block_L2")
+    triples = helpers.load_graph("fb237_valid_test")
+    oacts = oracle.encoder_forward(c["params"], triples, c["V"], c["L"], "block", mode="test")
+    eng = native.Engine(c["V"], c["R"], c["d"], c["L"], "block", c["nb"], max_edges=len(triples))
+    try:
+        eng.set_params(c["params"])
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        codes = eng.codes()
+    finally:
+        eng.close()
+    assert float(np.abs(codes - oacts[-1]).max()) <= FWD_ATOL
+
+
+# ------------------------------------------------------------------ relation sharding on one GPU
+@pytest.mark.parametrize("world", [2, 4])
+def test_relation_sharding_with_host_exchange(native, world):
+    """world ranks as separate contexts on ONE device; the all-reduce is done by the test through
+    read_buffer/write_buffer (the collective's test double).  Result must equal the unsharded run."""
+    V, R, d, L, nb, E = 90, 10, 20, 2, 4, 600
+    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=12)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
+    from relationprediction_amd.sharding import lpt_partition
+    owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
+    engs = [native.Engine(V, R, d, L, "block", nb, max_edges=E, rank=r, world=world) for r in range(world)]
+    try:
+        for e in engs:
+            e.set_params(params)
+            e.set_relation_owner(owner)
+            e.set_graph(triples)
+            e.forward_begin(train=True, masks=masks)
+        for l in range(1, L + 1):
+            for e in engs:
+                e.forward_layer_partial(l)
+            total = sum(e.read_buffer(native.BUF_EXCHANGE) for e in engs)
+            for e in engs:
+                e.write_buffer(native.BUF_EXCHANGE, total)
+                e.forward_layer_finish(l)
+        for e in engs:
+            assert float(np.abs(e.codes() - oacts[-1]).max()) <= FWD_ATOL
+        dbufs = [e.to_device(dcodes) for e in engs]
+        for e, b in zip(engs, dbufs):
+            e.backward_begin(b)
+        for l in range(L, 0, -1):
+            for e in engs:
+                e.backward_layer_partial(l)
+            tot = sum(e.read_buffer(native.BUF_EXCHANGE) for e in engs)
+            totw = sum(e.read_buffer(native.BUF_DSELF_EXCHANGE) for e in engs)
+            for e in engs:
+                e.write_buffer(native.BUF_EXCHANGE, tot)
+                e.write_buffer(native.BUF_DSELF_EXCHANGE, totw)
+                e.backward_layer_finish(l)
+        for e in engs:
+            e.backward_end()
+        for r, e in enumerate(engs):
+            g = e.get_grads()
+            for name in ["W_emb", "b_emb", "W_self1", "W_self2"]:
+                assert_close(g[name], ograds[name], rel=2e-4, name="rank%d %s" % (r, name))
+            for name in ["W_f1", "W_b1", "W_f2", "W_b2"]:       # only the owner holds a relation's gradient
+                mine = owner == r
+                assert_close(g[name][mine], ograds[name][mine], rel=2e-4, name="rank%d %s" % (r, name))
+                assert not g[name][~mine].any()
+        for b in dbufs:
+            b.free()
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_rccl_single_rank_communicator(native):
+    """world == 1 communicator: proves librccl loads, the id/init/all-reduce path runs on the
+    context's stream and leaves data unchanged (sum over one rank)."""
+    eng = native.Engine(32, 3, 8, 1, "block", 2, max_edges=4)
+    try:
+        uid = native.Engine.comm_unique_id()
+        eng.comm_init(uid)
+        x = np.arange(1000, dtype=np.float32)
+        buf = eng.to_device(x)
+        eng.comm_allreduce_sum(buf, x.size)
+        np.testing.assert_array_equal(buf.download(np.float32, x.shape), x)
+        buf.free()
+    finally:
+        eng.close()
