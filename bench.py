@@ -71,11 +71,12 @@ def main():
 
     from relationprediction_amd import _native
     from relationprediction_amd.sharding import lpt_partition
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers  # seeded workload construction shared with the parity tests
 
     graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[args.workload]
-    triples = helpers.load_graph(graph_name)
+    # real graph structure committed as a fixture (tests/golden/make_golden.py reads the reference's
+    # data files with the reference's formats; /root/reference itself is not needed at run time)
+    with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
+        triples = np.ascontiguousarray(z[graph_name].astype(np.int32))
     assert triples.shape[0] == E_g
     from relationprediction_amd.common.shared_functions import init_encoder_params
     params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
