@@ -218,6 +218,12 @@ rgcn_status rgcn_debug_gemm(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b, int
                             int32_t K, int32_t split_k, const float* a_host, const float* b_host,
                             float* c_host);
 
+/* Same contraction on device copies of the operands, `iters` back-to-back launches timed with HIP
+ * events on the context's stream; *avg_ms = mean time of one product (incl. the split-K reduce). */
+rgcn_status rgcn_debug_gemm_time(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b, int32_t M, int32_t N,
+                                 int32_t K, int32_t split_k, int32_t iters, const float* a_host,
+                                 const float* b_host, float* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,8 @@ _SIGS = {
     "rgcn_profile_get": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rgcn_debug_gemm": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rgcn_debug_gemm_time": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, _P, _P, C.POINTER(C.c_float)]),
 }
 
 
@@ -396,6 +398,16 @@ class Engine:
             out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
                         "alg_bytes": by.value, "alg_flops": fl.value})
         return out
+
+    def debug_gemm_time(self, a, b, trans_a=False, trans_b=False, split_k=0, iters=20):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        K, M = (a.shape if trans_a else a.shape[::-1])
+        N = b.shape[0] if trans_b else b.shape[1]
+        ms = C.c_float()
+        self._check(self.lib.rgcn_debug_gemm_time(self.ctx, int(trans_a), int(trans_b), M, N, K, int(split_k),
+                                                  int(iters), _ptr(a), _ptr(b), C.byref(ms)))
+        return float(ms.value)
 
     def debug_gemm(self, a, b, trans_a=False, trans_b=False, split_k=0):
         a = np.ascontiguousarray(a, dtype=np.float32)

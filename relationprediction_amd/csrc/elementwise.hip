@@ -151,22 +151,33 @@ __global__ void k_materialize_mask(uint8_t* out, int64_t n, DropSpec ds) {
 
 // column sums of a [rows, cols] matrix, deterministic two-stage reduction:
 // stage 1: block (bx, by) sums rows [by*RB, by*RB+RB) for 256 columns -> part[by][col]
-constexpr int kColRowsPerBlock = 128;
+// (4 independent accumulators per thread keep 4 row loads in flight)
+constexpr int kColRowsPerBlock = 64;
 __global__ void k_colsum_part(const float* __restrict__ in, float* __restrict__ part, int rows, int cols) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= cols) return;
   const int r0 = blockIdx.y * kColRowsPerBlock;
   const int r1 = min(rows, r0 + kColRowsPerBlock);
-  float acc = 0.0f;
-  for (int r = r0; r < r1; ++r) acc += in[(size_t)r * cols + col];
-  part[(size_t)blockIdx.y * cols + col] = acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    const float* p = in + (size_t)r * cols + col;
+    a0 += p[0]; a1 += p[cols]; a2 += p[2 * (size_t)cols]; a3 += p[3 * (size_t)cols];
+  }
+  for (; r < r1; ++r) a0 += in[(size_t)r * cols + col];
+  part[(size_t)blockIdx.y * cols + col] = (a0 + a1) + (a2 + a3);
 }
 __global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int nparts, int cols) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= cols) return;
-  float acc = 0.0f;
-  for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * cols + col];
-  out[col] = acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = 0;
+  for (; p + 4 <= nparts; p += 4) {
+    const float* q = part + (size_t)p * cols + col;
+    a0 += q[0]; a1 += q[cols]; a2 += q[2 * (size_t)cols]; a3 += q[3 * (size_t)cols];
+  }
+  for (; p < nparts; ++p) a0 += part[(size_t)p * cols + col];
+  out[col] = (a0 + a1) + (a2 + a3);
 }
 
 int grid_for(int64_t n, int threads) {
@@ -264,7 +275,7 @@ rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int c
   ProfScope ps(c, "bias_grad_colsum", 4.0 * rows * cols, 0);
   hipLaunchKernelGGL(k_colsum_part, dim3((cols + 255) / 256, nparts), dim3(256), 0, c->stream, in,
                      c->colsum_part, rows, cols);
-  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 255) / 256), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(64), 0, c->stream,
                      c->colsum_part, out, nparts, cols);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;

@@ -6,30 +6,28 @@
 // gfx950 has no TF32/xf32; `v_mfma_f32_32x32x2_f32` is exact fp32 (bitwise an fmaf chain) at the
 // fp32 vector rate (157 TF peak), which is what the 1e-4 parity bar needs.
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA
-// 32x32 tiles = 64 accumulator registers), BK = 16, register-staged double-buffered LDS.
-// Operands come in two storage flavours, handled without any transposition in flight:
-//   k-contiguous ("KC",  X[row][k]):  LDS tile [128][16] with row stride 20 dwords (bank-conflict
+// Tiling: BM x BN output tile per workgroup of WGM x WGN waves, each wave owning a
+// (BM/WGM) x (BN/WGN) sub-tile as TM x TN MFMA 32x32 tiles, BK-deep register-staged
+// double-buffered LDS.  Operands come in two storage flavours, handled without any transposition:
+//   k-contiguous ("KC",  X[row][k]):  LDS tile [rows][BK] with row stride BK+4 dwords (bank-conflict
 //        free for ds_read_b128 in its 16-lane groups); a lane fetches 4 consecutive k with one
 //        ds_read_b128.
-//   row-contiguous ("RC", X[k][row]): LDS tile [16][128]; a lane fetches its 4 k values with four
+//   row-contiguous ("RC", X[k][row]): LDS tile [BK][rows]; a lane fetches its 4 k values with four
 //        conflict-free ds_read_b32.
 // Within each group of 8 k, MFMA #t consumes k = {t, 4+t} (lane half h supplies k = 4h+t) for BOTH
 // operands, so the permuted k order is consistent and only changes the fp32 summation order.
 //   NN (forward):   A = H   [M,K] KC,  B = W   [K,N] RC
 //   NT (dH):        A = dS  [M,K] KC,  B = W   [N,K] KC
 //   TN (dW):        A = H   [K,M] RC,  B = dS  [K,N] RC, split over K into slabs + ordered reduce
+// Workgroup ids are remapped so that the tiles sharing an A row-panel (and, for split-K, the tiles
+// of one K slab) run on the same XCD and hit its L2 instead of re-fetching the panel over the fabric.
+#include <cstdlib>
+
 #include "rgcn_internal.h"
 
 namespace rgcn {
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDK = 20;    // row stride (dwords) of a k-contiguous tile
-constexpr int LDR = 128;   // row stride (dwords) of a row-contiguous tile
-constexpr int TILE_KC = BM * LDK;   // 2560 floats
-constexpr int TILE_RC = BK * LDR;   // 2048 floats
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -37,112 +35,139 @@ struct GemmArgs {
   const float* A;
   const float* B;
   float* C;          // output (or slab base when split_k > 1)
+  const float* zeros;  // >= 16 zero bytes, 16-byte aligned
   int M, N, K;
   int lda, ldb, ldc;
   int k_per_split;   // multiple of BK
-  int vecA, vecB;    // 16-byte vector loads legal
+  int tiles_m, tiles_n, splits;
+  int swizzle;       // XCD-aware workgroup remap
 };
 
-// ---- global -> registers (one k-tile of one operand: 512 float4, 2 per thread) -----------------
-template <bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int rows, int kdim,
-                                          int row0, int k0, int kend, int vec, float4 (&r)[2]) {
+template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_;
+  static constexpr int NT = 64 * WGM * WGN;
+  static constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  static constexpr int LDK = BK + 4;
+  static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are multiples of 32");
+  static_assert(BK % 8 == 0, "BK multiple of 8");
+  static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "whole float4 passes");
+};
+
+// ---- global -> registers: one k-tile of one operand, ROWS x BK floats, P float4 per thread ------
+// Branch-free and select-free on the DATA side: an out-of-range lane redirects its ADDRESS to a
+// small zero-filled buffer, so the loads issue back-to-back at the top of the k-loop and nothing
+// touches their results until the LDS store at the bottom (a guarded load, or a select on the loaded
+// value, makes hipcc wait vmcnt(0) right behind the load and serialises HBM latency with the MFMAs).
+// VEC: 16-byte loads are legal and validity is all-or-nothing per float4 (K resp. rows % 4 == 0).
+template <bool KC, int ROWS, int BK, int NT, int P, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ X, const float* __restrict__ zeros,
+                                          int ld, int rows, int row0, int k0, int kend,
+                                          float4 (&r)[P]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int f = t + 256 * p;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < P; ++p) {
+    const int f = t + NT * p;
+    int row, k;
+    size_t off;
     if constexpr (KC) {
-      const int row = row0 + (f >> 2);
-      const int k = k0 + ((f & 3) << 2);
-      if (row < rows) {
-        const float* src = X + (size_t)row * ld + k;
-        if (vec && k + 3 < kend) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (k + 0 < kend) v.x = src[0];
-          if (k + 1 < kend) v.y = src[1];
-          if (k + 2 < kend) v.z = src[2];
-          if (k + 3 < kend) v.w = src[3];
-        }
-      }
+      constexpr int Q = BK / 4;
+      row = row0 + f / Q;
+      k = k0 + (f % Q) * 4;
+      off = (size_t)row * ld + k;
     } else {
-      const int k = k0 + (f >> 5);
-      const int row = row0 + ((f & 31) << 2);
-      if (k < kend) {
-        const float* src = X + (size_t)k * ld + row;
-        if (vec && row + 3 < rows) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (row + 0 < rows) v.x = src[0];
-          if (row + 1 < rows) v.y = src[1];
-          if (row + 2 < rows) v.z = src[2];
-          if (row + 3 < rows) v.w = src[3];
-        }
-      }
+      constexpr int Q = ROWS / 4;
+      k = k0 + f / Q;
+      row = row0 + (f % Q) * 4;
+      off = (size_t)k * ld + row;
     }
-    r[p] = v;
+    if constexpr (VEC) {
+      const bool ok = row < rows && k < kend;
+      const float* src = ok ? X + off : zeros;
+      r[p] = *reinterpret_cast<const float4*>(src);
+    } else {
+      // element e advances along the contiguous dimension: k for KC, row for RC
+      float e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = KC ? (row < rows && k + q < kend) : (k < kend && row + q < rows);
+        const float* src = ok ? X + off + q : zeros;
+        e[q] = *src;
+      }
+      r[p] = make_float4(e[0], e[1], e[2], e[3]);
+    }
   }
-  (void)kdim;
 }
 
 // ---- registers -> LDS -------------------------------------------------------------------------
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&r)[2]) {
+template <bool KC, int ROWS, int BK, int NT, int P>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&r)[P]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int f = t + 256 * p;
+  for (int p = 0; p < P; ++p) {
+    const int f = t + NT * p;
     int off;
-    if constexpr (KC) off = (f >> 2) * LDK + ((f & 3) << 2);
-    else off = (f >> 5) * LDR + ((f & 31) << 2);
+    if constexpr (KC) off = (f / (BK / 4)) * (BK + 4) + (f % (BK / 4)) * 4;
+    else off = (f / (ROWS / 4)) * ROWS + (f % (ROWS / 4)) * 4;
     *reinterpret_cast<float4*>(lds + off) = r[p];
   }
 }
 
 // ---- LDS -> MFMA fragments: 4 k values (k = 8*kk + 4*h + t, t = 0..3) of row `row` ------------
-template <bool KC>
+template <bool KC, int ROWS, int BK>
 __device__ __forceinline__ void load_frag(const float* __restrict__ lds, int row, int kk, int h,
                                           float (&f)[4]) {
   if constexpr (KC) {
-    const float4 v = *reinterpret_cast<const float4*>(lds + row * LDK + 8 * kk + 4 * h);
+    const float4 v = *reinterpret_cast<const float4*>(lds + row * (BK + 4) + 8 * kk + 4 * h);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
-    const float* p = lds + (8 * kk + 4 * h) * LDR + row;
-    f[0] = p[0]; f[1] = p[LDR]; f[2] = p[2 * LDR]; f[3] = p[3 * LDR];
+    const float* p = lds + (8 * kk + 4 * h) * ROWS + row;
+    f[0] = p[0]; f[1] = p[ROWS]; f[2] = p[2 * ROWS]; f[3] = p[3 * ROWS];
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
-  constexpr int TA = A_KC ? TILE_KC : TILE_RC;
-  constexpr int TB = B_KC ? TILE_KC : TILE_RC;
+template <bool A_KC, bool B_KC, bool VEC, class CF>
+__global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
+  constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, NT = CF::NT, TM = CF::TM, TN = CF::TN;
+  constexpr int TA = A_KC ? BM * CF::LDK : BK * BM;
+  constexpr int TB = B_KC ? BN * CF::LDK : BK * BN;
+  constexpr int PA = BM * BK / 4 / NT, PB = BN * BK / 4 / NT;
   __shared__ __attribute__((aligned(16))) float lds[2 * (TA + TB)];
-  // buffer b of A lives at lds + b*(TA+TB), buffer b of B right behind it
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int ks = blockIdx.z * g.k_per_split;
+  // ---- workgroup -> (k-slab, row tile, column tile); XCD-aware so that neighbours share an L2
+  int wg = blockIdx.x;
+  const int total = g.tiles_m * g.tiles_n * g.splits;
+  if (g.swizzle) {
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int q = total >> 3, r = total & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_split = g.tiles_m * g.tiles_n;
+  const int z = wg / per_split;
+  const int rem = wg - z * per_split;
+  const int m0 = (rem / g.tiles_n) * BM, n0 = (rem % g.tiles_n) * BN;
+  const int ks = z * g.k_per_split;
   const int ke = min(g.K, ks + g.k_per_split);
   const int nkt = (ke - ks + BK - 1) / BK;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave / CF::WGN) * (TM * 32), wn = (wave % CF::WGN) * (TN * 32);
   const int li = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  float4 ra[2], rb[2];
+  float4 ra[PA], rb[PB];
   if (nkt > 0) {
-    load_tile<A_KC>(g.A, g.lda, g.M, g.K, m0, ks, ke, g.vecA, ra);
-    load_tile<B_KC>(g.B, g.ldb, g.N, g.K, n0, ks, ke, g.vecB, rb);
-    store_tile<A_KC>(lds, ra);
-    store_tile<B_KC>(lds + TA, rb);
+    load_tile<A_KC, BM, BK, NT, PA, VEC>(g.A, g.zeros, g.lda, g.M, m0, ks, ke, ra);
+    load_tile<B_KC, BN, BK, NT, PB, VEC>(g.B, g.zeros, g.ldb, g.N, n0, ks, ke, rb);
+    store_tile<A_KC, BM, BK, NT, PA>(lds, ra);
+    store_tile<B_KC, BN, BK, NT, PB>(lds + TA, rb);
   }
   __syncthreads();
 
@@ -150,39 +175,39 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
     if (more) {   // next tile's global loads fly under this tile's MFMAs
-      load_tile<A_KC>(g.A, g.lda, g.M, g.K, m0, ks + (kt + 1) * BK, ke, g.vecA, ra);
-      load_tile<B_KC>(g.B, g.ldb, g.N, g.K, n0, ks + (kt + 1) * BK, ke, g.vecB, rb);
+      load_tile<A_KC, BM, BK, NT, PA, VEC>(g.A, g.zeros, g.lda, g.M, m0, ks + (kt + 1) * BK, ke, ra);
+      load_tile<B_KC, BN, BK, NT, PB, VEC>(g.B, g.zeros, g.ldb, g.N, n0, ks + (kt + 1) * BK, ke, rb);
     }
     const float* a_lds = lds + cur * (TA + TB);
     const float* b_lds = a_lds + TA;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      float fa[2][4], fb[2][4];
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float fa[TM][4], fb[TN][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) load_frag<A_KC>(a_lds, wm + 32 * i + li, kk, h, fa[i]);
+      for (int i = 0; i < TM; ++i) load_frag<A_KC, BM, BK>(a_lds, wm + 32 * i + li, kk, h, fa[i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) load_frag<B_KC>(b_lds, wn + 32 * j + li, kk, h, fb[j]);
+      for (int j = 0; j < TN; ++j) load_frag<B_KC, BN, BK>(b_lds, wn + 32 * j + li, kk, h, fb[j]);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      store_tile<A_KC>(lds + (cur ^ 1) * (TA + TB), ra);
-      store_tile<B_KC>(lds + (cur ^ 1) * (TA + TB) + TA, rb);
+      store_tile<A_KC, BM, BK, NT, PA>(lds + (cur ^ 1) * (TA + TB), ra);
+      store_tile<B_KC, BN, BK, NT, PB>(lds + (cur ^ 1) * (TA + TB) + TA, rb);
     }
     __syncthreads();
   }
 
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
-  float* C = g.C + (size_t)blockIdx.z * g.M * g.ldc;   // slab z (ldc == N for slabs)
+  float* C = g.C + (size_t)z * g.M * g.ldc;   // slab z (ldc == N for slabs)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn + 32 * j + li;
       if (col < g.N) {
 #pragma unroll
@@ -205,7 +230,31 @@ __global__ void k_splitk_reduce(const float* __restrict__ slab, float* __restric
   C[(size_t)row * ldc + col] = acc;
 }
 
-bool vec_ok(const float* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld % 4) == 0; }
+// 16-byte loads legal and float4 validity all-or-nothing: aligned base, ld % 4 == 0, and the
+// contiguous extent (K for a k-contiguous operand, the row count for a row-contiguous one) % 4 == 0.
+bool vec_ok(const float* p, int ld, int contiguous_extent) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld % 4) == 0 && (contiguous_extent % 4) == 0 &&
+         contiguous_extent >= 4;
+}
+
+template <class CF, bool VEC>
+void launch_v(rgcn_ctx* c, bool a_kc, bool b_kc, GemmArgs& g) {
+  g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
+  g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(CF::NT);
+  if (a_kc && !b_kc) hipLaunchKernelGGL((k_gemm_f32<true, false, VEC, CF>), grid, block, 0, c->stream, g);
+  else if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm_f32<true, true, VEC, CF>), grid, block, 0, c->stream, g);
+  else hipLaunchKernelGGL((k_gemm_f32<false, false, VEC, CF>), grid, block, 0, c->stream, g);
+}
+template <class CF>
+void launch(rgcn_ctx* c, bool a_kc, bool b_kc, GemmArgs& g, bool vec) {
+  if (vec) launch_v<CF, true>(c, a_kc, b_kc, g); else launch_v<CF, false>(c, a_kc, b_kc, g);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
 
 }  // namespace
 
@@ -214,16 +263,21 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
                      int split_k) {
   if (M <= 0 || N <= 0) return RGCN_OK;
   if (a_kc == false && b_kc == true) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "gemm TT form not instantiated");
+  static const int variant = env_int("RGCN_GEMM_VARIANT", 0);     // tuning knob (tools/gemm_sweep.py)
+  static const int swizzle = env_int("RGCN_GEMM_SWIZZLE", 1);
+  const int bk = (variant == 1 || variant == 3 || variant == 5) ? 32 : 16;
   GemmArgs g;
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-  g.vecA = vec_ok(A, lda) ? 1 : 0;
-  g.vecB = vec_ok(B, ldb) ? 1 : 0;
+  const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N);
+  g.swizzle = swizzle;
+  g.zeros = c->zeros;
   if (split_k < 1) split_k = 1;
   int kps = (K + split_k - 1) / split_k;
-  kps = ((kps + BK - 1) / BK) * BK;
-  if (kps < BK) kps = BK;
+  kps = ((kps + bk - 1) / bk) * bk;
+  if (kps < bk) kps = bk;
   split_k = K > 0 ? (K + kps - 1) / kps : 1;
   g.k_per_split = kps;
+  g.splits = split_k;
   const bool slabs = split_k > 1;
   if (slabs) {
     if ((size_t)split_k * M * N > c->slab_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: split-K slab too small");
@@ -231,12 +285,22 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   } else {
     g.C = C; g.ldc = ldc;
   }
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k), block(256);
   {
     ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * N * K);
-    if (a_kc && !b_kc) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, block, 0, c->stream, g);
-    else if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, block, 0, c->stream, g);
-    else hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, block, 0, c->stream, g);
+    switch (variant) {
+      case 1: launch<Cfg<128, 128, 32, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 2: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;  // == default
+      case 3: launch<Cfg<128, 128, 32, 4, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 4: launch<Cfg<64, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 5: launch<Cfg<64, 128, 32, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 6: launch<Cfg<128, 64, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 7: launch<Cfg<64, 64, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
+      case 9: launch<Cfg<256, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;
+      case 10: launch<Cfg<128, 256, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
+      case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
+      default: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;
+    }
     RGCN_HIP(c, hipGetLastError());
   }
   if (slabs) {

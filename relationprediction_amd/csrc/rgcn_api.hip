@@ -138,7 +138,7 @@ static void free_all(rgcn_ctx* c) {
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
-  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own);
+  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own); F(c->zeros);
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->t0) (void)hipEventDestroy(c->t0);
@@ -246,7 +246,8 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     if ((size_t)p.count > stage) stage = (size_t)p.count;
   c->stage_floats = stage;
   RGCN_TRY(dmalloc(c, &c->stage, stage, false));
-  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 127) / 128) * d));
+  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 63) / 64) * d));
+  RGCN_TRY(dmalloc(c, &c->zeros, 64));
   RGCN_TRY(graph_alloc(c));
   {
     std::vector<int32_t> owner(c->R);
@@ -744,6 +745,40 @@ rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int3
     s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
     if (s != RGCN_OK) break;
     s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N);
+  } while (0);
+  if (A) (void)hipFree(A);
+  if (B) (void)hipFree(B);
+  if (C) (void)hipFree(C);
+  return s;
+}
+
+rgcn_status rgcn_debug_gemm_time(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
+                                 int32_t split_k, int32_t iters, const float* a_host,
+                                 const float* b_host, float* avg_ms) {
+  RGCN_NEED(c);
+  if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !a_host || !b_host || !avg_ms)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  if (ta && tb) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "TT form not instantiated");
+  float *A = nullptr, *B = nullptr, *C = nullptr;
+  rgcn_status s = RGCN_OK;
+  do {
+    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
+    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
+    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
+    int sk = split_k > 0 ? split_k : auto_split_k(M, N, K);
+    if ((size_t)sk * M * N > c->slab_floats) sk = 1;
+    for (int it = 0; it < 3 && s == RGCN_OK; ++it)
+      s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
+    if (s != RGCN_OK) break;
+    if ((s = rgcn_timer_start(c)) != RGCN_OK) break;
+    for (int it = 0; it < iters && s == RGCN_OK; ++it)
+      s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
+    if (s != RGCN_OK) break;
+    float ms = 0.f;
+    if ((s = rgcn_timer_stop(c, &ms)) != RGCN_OK) break;
+    *avg_ms = ms / iters;
   } while (0);
   if (A) (void)hipFree(A);
   if (B) (void)hipFree(B);

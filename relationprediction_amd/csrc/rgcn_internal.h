@@ -160,6 +160,7 @@ struct rgcn_ctx {
   size_t stage_floats = 0;
   uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
   float* colsum_part = nullptr;
+  float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
 
   rgcn::GraphBufs g;
   int chunk = 96;                        // messages per relation chunk
