@@ -236,10 +236,10 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
   const int R2 = 2 * c->R;
   if (c->g.E > 0) {
     const int nchunks = max_chunks(c);
-    if ((size_t)nchunks * per_rel > c->slab_floats)
+    if ((size_t)nchunks * per_rel > c->slab_dw_floats)
       RGCN_FAIL(c, RGCN_ERR_STATE, "internal: dW slab buffer too small");
     MsgArgs a;
-    a.Hin = Hin; a.D = D; a.W = c->layers[layer].wrel; a.out = Zbuf; a.slab = c->slab;
+    a.Hin = Hin; a.D = D; a.W = c->layers[layer].wrel; a.out = Zbuf; a.slab = c->slab_dw;
     a.m_src = c->g.m_src; a.m_dst = c->g.m_dst; a.m_slot = c->g.m_sslot; a.m_norm = c->g.m_norm;
     a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr;
     a.R2 = R2; a.nb = c->nb; a.d = c->d; a.chunk = c->chunk; a.G = c->msg_slots;
@@ -258,7 +258,7 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
     const int64_t n = (int64_t)R2 * per_rel;
     ProfScope ps(c, "block_dw_reduce", 8.0 * n, 0);
     hipLaunchKernelGGL(k_block_dw_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->slab, c->g.chunk_ptr, c->layers[layer].grel, R2, per_rel);
+                       c->slab_dw, c->g.chunk_ptr, c->layers[layer].grel, R2, per_rel);
     RGCN_HIP(c, hipGetLastError());
   }
   return RGCN_OK;

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
   int beg = 0, end = 0;
   if (a.msg != nullptr) {
     beg = a.row_ptr[v];
-    end = a.row_ptr[v + 1];
+    end = a.row_end[v];
   }
   const bool base_valid = a.base != nullptr && v >= a.row_lo && v < a.row_hi;
   for (int cidx = lane; cidx < nvec; cidx += TPR) {
@@ -110,6 +110,72 @@ __global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
   }
 }
 
+// One workgroup per long row: 8 slot-lanes x 128 column-lanes; each slot-lane strides over the row's
+// slots with 4 independent loads in flight, LDS combines the 8 partial sums in a fixed order, and
+// the result replaces the row's first slot (combine() then reads exactly one slot for this row).
+template <int VEC>
+__global__ void __launch_bounds__(1024) k_long_row_reduce(float* __restrict__ msg,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ long_rows,
+                                                          const int32_t* __restrict__ nlong, int d) {
+  __shared__ float red[8][128 * VEC];
+  const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  const int nvec = d / VEC;
+  const int n = *nlong;
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {   // few long rows: a small persistent grid
+  const int v = long_rows[b];
+  const int beg = row_ptr[v], end = row_ptr[v + 1];
+  for (int c0 = 0; c0 < nvec; c0 += 128) {
+    const int cidx = c0 + cl;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    if (cidx < nvec) {
+      const float* mp = msg + (size_t)cidx * VEC;
+      int s = beg + sl;
+      for (; s + 8 * 15 < end; s += 8 * 16) {   // 16 independent loads in flight per lane
+        float m[16][VEC];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * d, m[u]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
+      }
+      for (; s + 24 < end; s += 32) {
+        float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
+        vload<VEC>(mp + (size_t)(s + 0) * d, m0);
+        vload<VEC>(mp + (size_t)(s + 8) * d, m1);
+        vload<VEC>(mp + (size_t)(s + 16) * d, m2);
+        vload<VEC>(mp + (size_t)(s + 24) * d, m3);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
+      }
+      for (; s < end; s += 8) {
+        float m0[VEC];
+        vload<VEC>(mp + (size_t)s * d, m0);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+    __syncthreads();
+    if (sl == 0 && cidx < nvec) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float t = red[0][cl * VEC + k];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
+        acc[k] = t;
+      }
+      vstore<VEC>(msg + (size_t)beg * d + (size_t)cidx * VEC, acc);
+    }
+    __syncthreads();
+  }
+  }
+}
+
 template <int VEC>
 __global__ void k_input_fwd(const float* __restrict__ W, const float* __restrict__ b,
                             float* __restrict__ H, int64_t nvec_total, int d) {
@@ -149,35 +215,52 @@ __global__ void k_materialize_mask(uint8_t* out, int64_t n, DropSpec ds) {
   for (; i < n; i += stride) out[i] = drop_scale(ds, (size_t)i) != 0.0f ? 1 : 0;
 }
 
-// column sums of a [rows, cols] matrix, deterministic two-stage reduction:
-// stage 1: block (bx, by) sums rows [by*RB, by*RB+RB) for 256 columns -> part[by][col]
-// (4 independent accumulators per thread keep 4 row loads in flight)
-constexpr int kColRowsPerBlock = 64;
-__global__ void k_colsum_part(const float* __restrict__ in, float* __restrict__ part, int rows, int cols) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
-  const int r0 = blockIdx.y * kColRowsPerBlock;
-  const int r1 = min(rows, r0 + kColRowsPerBlock);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int r = r0;
-  for (; r + 4 <= r1; r += 4) {
-    const float* p = in + (size_t)r * cols + col;
-    a0 += p[0]; a1 += p[cols]; a2 += p[2 * (size_t)cols]; a3 += p[3 * (size_t)cols];
+// column sums of a [rows, cols] matrix, deterministic two-stage reduction.
+// stage 1: block (bx, by): 64 column lanes x 4 row lanes; rows [by*32, by*32+32): every thread keeps
+// 8 independent row loads in flight, the 4 row lanes combine through LDS -> part[by][col].
+// stage 2: 64 column lanes x 16 part lanes per block sum the partials in a fixed order.
+constexpr int kColRowsPerBlock = 32;
+__global__ void __launch_bounds__(256) k_colsum_part(const float* __restrict__ in, float* __restrict__ part,
+                                                    int rows, int cols) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * kColRowsPerBlock + rl * 8;
+  float acc = 0.f;
+  if (col < cols) {
+    float m[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m[u] = (r0 + u < rows) ? in[(size_t)(r0 + u) * cols + col] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += m[u];
   }
-  for (; r < r1; ++r) a0 += in[(size_t)r * cols + col];
-  part[(size_t)blockIdx.y * cols + col] = (a0 + a1) + (a2 + a3);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && col < cols)
+    part[(size_t)blockIdx.y * cols + col] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
 }
-__global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int nparts, int cols) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
+__global__ void __launch_bounds__(1024) k_colsum_final(const float* __restrict__ part, float* __restrict__ out,
+                                                      int nparts, int cols) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int p = 0;
-  for (; p + 4 <= nparts; p += 4) {
-    const float* q = part + (size_t)p * cols + col;
-    a0 += q[0]; a1 += q[cols]; a2 += q[2 * (size_t)cols]; a3 += q[3 * (size_t)cols];
+  if (col < cols) {
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      const float* q = part + (size_t)p * cols + col;
+      a0 += q[0]; a1 += q[(size_t)16 * cols]; a2 += q[(size_t)32 * cols]; a3 += q[(size_t)48 * cols];
+    }
+    for (; p < nparts; p += 16) a0 += part[(size_t)p * cols + col];
   }
-  for (; p < nparts; ++p) a0 += part[(size_t)p * cols + col];
-  out[col] = (a0 + a1) + (a2 + a3);
+  red[pl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (pl == 0 && col < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    out[col] = t;
+  }
 }
 
 int grid_for(int64_t n, int threads) {
@@ -235,6 +318,22 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double a
   return RGCN_OK;
 }
 
+rgcn_status long_row_reduce(rgcn_ctx* c, float* msg) {
+  if (c->g.E == 0) return RGCN_OK;
+  int64_t blocks = 2 * c->g.E / kLongRow + 1;
+  if (blocks > c->g.long_cap) blocks = c->g.long_cap;
+  if (blocks > 128) blocks = 128;
+  ProfScope ps(c, "long_row_reduce", 0, 0);
+  if (c->d % 4 == 0 && aligned16(msg))
+    hipLaunchKernelGGL((k_long_row_reduce<4>), dim3((unsigned)blocks), dim3(1024), 0, c->stream, msg,
+                       c->g.row_ptr, c->g.long_rows, c->g.nlong, c->d);
+  else
+    hipLaunchKernelGGL((k_long_row_reduce<1>), dim3((unsigned)blocks), dim3(1024), 0, c->stream, msg,
+                       c->g.row_ptr, c->g.long_rows, c->g.nlong, c->d);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
 rgcn_status input_forward(rgcn_ctx* c) {
   const int64_t n = (int64_t)c->V * c->d;
   ProfScope ps(c, "input_fwd", 8.0 * n, 0);
@@ -273,9 +372,9 @@ rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, 
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols) {
   const int nparts = (rows + kColRowsPerBlock - 1) / kColRowsPerBlock;
   ProfScope ps(c, "bias_grad_colsum", 4.0 * rows * cols, 0);
-  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 255) / 256, nparts), dim3(256), 0, c->stream, in,
+  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nparts), dim3(256), 0, c->stream, in,
                      c->colsum_part, rows, cols);
-  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(64), 0, c->stream,
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(1024), 0, c->stream,
                      c->colsum_part, out, nparts, cols);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;

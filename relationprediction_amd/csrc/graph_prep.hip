@@ -105,6 +105,21 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
   if (tid == 0) job.out[job.n] = carry_s;
 }
 
+// row_end + compacted list of long rows (order of the list is irrelevant: rows are independent)
+__global__ void k_rows(const int32_t* __restrict__ row_ptr, int V, int32_t* row_end, int32_t* long_rows,
+                       int32_t* nlong, int cap) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int beg = row_ptr[v], end = row_ptr[v + 1];
+  if (end - beg > kLongRow) {
+    const int i = atomicAdd(nlong, 1);
+    if (i < cap) long_rows[i] = v;
+    row_end[v] = beg + 1;
+  } else {
+    row_end[v] = end;
+  }
+}
+
 __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
                        const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
                        uint32_t* keyr, int32_t* valr) {
@@ -187,12 +202,17 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   GraphBufs& g = c->g;
   const size_t V = c->V, R2 = 2 * (size_t)c->R, M = 2 * (size_t)c->cfg.max_edges;
   RGCN_TRY(dalloc(c, &g.triples, 3 * (size_t)c->cfg.max_edges));
-  g.counters_bytes = (3 * V + R2) * sizeof(int32_t);
-  RGCN_TRY(dalloc(c, &g.counters, 3 * V + R2));
+  g.counters_bytes = (3 * V + R2 + 1) * sizeof(int32_t);
+  RGCN_TRY(dalloc(c, &g.counters, 3 * V + R2 + 1));
   g.indeg = g.counters;
   g.outdeg = g.counters + V;
   g.cnt = g.counters + 2 * V;
   g.relcnt = g.counters + 3 * V;
+  g.nlong = g.counters + 3 * V + R2;
+  g.long_cap = (int32_t)(M / kLongRow + 1);
+  RGCN_TRY(dalloc(c, &g.long_rows, (size_t)g.long_cap));
+  RGCN_TRY(dalloc(c, &g.row_end, V));
+  RGCN_HIP(c, hipMemsetAsync(g.row_end, 0, sizeof(int32_t) * V, c->stream));
   RGCN_TRY(dalloc(c, &g.row_ptr, V + 1));
   RGCN_TRY(dalloc(c, &g.rel_ptr, R2 + 1));
   RGCN_TRY(dalloc(c, &g.chunk_ptr, R2 + 1));
@@ -229,12 +249,13 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   }
   g.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
   RGCN_HIP(c, hipMalloc(&g.sort_tmp, g.sort_tmp_bytes));
+  RGCN_HIP(c, hipMalloc(&c->sort_tmp2, g.sort_tmp_bytes));
   return RGCN_OK;
 }
 
 void graph_free(rgcn_ctx* c) {
   GraphBufs& g = c->g;
-  void* ptrs[] = {g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
+  void* ptrs[] = {g.long_rows, g.row_end, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.owner, g.errflag, g.sort_tmp};
   for (void* p : ptrs)
@@ -267,12 +288,24 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     ProfScope ps(c, "prep_scan", 8.0 * (V + 4 * R), 0);
     hipLaunchKernelGGL(k_exscan, dim3(njobs), dim3(kScanThreads), 0, c->stream, jobs);
   }
+  {
+    ProfScope ps(c, "prep_rows", 8.0 * V, 0);
+    hipLaunchKernelGGL(k_rows, dim3((V + T - 1) / T), dim3(T), 0, c->stream, g.row_ptr, V, g.row_end,
+                       g.long_rows, g.nlong, g.long_cap);
+  }
   if (E > 0) {
     const int M = 2 * E;
     {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
                          c->rank, g.keyv, g.valv, g.keyr, g.valr);
+    }
+    {   // the two sorts are independent: relation sort on a side stream
+      StreamScope side(c, 0);
+      ProfScope ps(c, "prep_sort_relation", 16.0 * M, 0);
+      size_t tb = g.sort_tmp_bytes;
+      RGCN_HIP(c, rocprim::radix_sort_pairs(c->sort_tmp2, tb, g.keyr, g.keyr_s, g.valr, g.permr,
+                                            (size_t)M, 0, bits_for((uint32_t)(2 * R)), c->stream));
     }
     {
       ProfScope ps(c, "prep_sort_vertex", 16.0 * M, 0);
@@ -281,15 +314,10 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                                             (size_t)M, 0, bits_for((uint32_t)V), c->stream));
     }
     {
-      ProfScope ps(c, "prep_sort_relation", 16.0 * M, 0);
-      size_t tb = g.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp, tb, g.keyr, g.keyr_s, g.valr, g.permr,
-                                            (size_t)M, 0, bits_for((uint32_t)(2 * R)), c->stream));
-    }
-    {
       ProfScope ps(c, "prep_pos", 8.0 * M, 0);
       hipLaunchKernelGGL(k_pos, dim3((M + T - 1) / T), dim3(T), 0, c->stream, g.permv, M, g.pos);
     }
+    RGCN_TRY(stream_join(c, 0));
     {
       ProfScope ps(c, "prep_build_msgs", 12.0 * E + 28.0 * M, 0);
       hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,

@@ -1,6 +1,7 @@
 // C ABI of librgcn.so (include/rgcn.h) and the per-layer orchestration of the encoder:
 //   forward  (MessageGcn.compute_vertex_embeddings, code/encoders/message_gcns/message_gcn.py:49-79)
 //   backward (tf.gradients(loss, weights), code/optimization/abstract.py:117-118; formulas SURVEY 8a a15)
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -40,8 +41,31 @@ ProfScope::~ProfScope() {
   if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, c->stream);
 }
 
+StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), active(false) {
+  if (!c->use_aux || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
+  if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess) return;
+  if (hipStreamWaitEvent(c->aux[k], c->ev_fork, 0) != hipSuccess) return;
+  c->stream = c->aux[k];
+  active = true;
+}
+StreamScope::~StreamScope() { c->stream = saved; }
+
+rgcn_status stream_join(rgcn_ctx* c, int k) {
+  if (!c->use_aux) return RGCN_OK;
+  RGCN_HIP(c, hipEventRecord(c->ev_join[k], c->aux[k]));
+  RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[k], 0));
+  return RGCN_OK;
+}
+
+static rgcn_status sync_all(rgcn_ctx* c) {
+  for (int k = 0; k < 2; ++k)
+    if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
+  RGCN_HIP(c, hipStreamSynchronize(c->main_stream));
+  return RGCN_OK;
+}
+
 static rgcn_status profile_collect(rgcn_ctx* c) {
-  RGCN_HIP(c, hipStreamSynchronize(c->stream));
+  RGCN_TRY(sync_all(c));
   for (ProfRec& r : c->prof) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -94,7 +118,8 @@ static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_lis
 static int auto_split_k(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   if (tiles >= 192) return 1;
-  int s = (512 + tiles - 1) / tiles;
+  static const int target = getenv("RGCN_SPLITK_TARGET") ? atoi(getenv("RGCN_SPLITK_TARGET")) : 512;
+  int s = (target + tiles - 1) / tiles;
   const int max_by_k = (K + 127) / 128;   // at least 128 of K per slab
   if (s > max_by_k) s = max_by_k;
   if (s > 64) s = 64;
@@ -104,6 +129,8 @@ static int auto_split_k(int M, int N, int K) {
 
 static rgcn_status check_dev_flag(rgcn_ctx* c) {
   int32_t flag = 0;
+  for (int k = 0; k < 2; ++k)
+    if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipMemcpyAsync(&flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   if (flag) {
@@ -128,7 +155,9 @@ static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes
 static void free_all(rgcn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 2; ++k)
+    if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
+  if (c->main_stream) (void)hipStreamSynchronize(c->main_stream);
   comm_destroy(c);
   graph_free(c);
   auto F = [](void* p) { if (p) (void)hipFree(p); };
@@ -138,12 +167,18 @@ static void free_all(rgcn_ctx* c) {
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
-  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own); F(c->zeros);
+  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->slab_dw); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own); F(c->zeros);
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (int k = 0; k < 2; ++k) {
+    if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->sort_tmp2) (void)hipFree(c->sort_tmp2);
+  if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
   delete c;
 }
 
@@ -179,6 +214,16 @@ static rgcn_status create_impl(rgcn_ctx* c) {
 
   RGCN_HIP(c, hipSetDevice(f.device));
   RGCN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->main_stream = c->stream;
+  for (int k = 0; k < 2; ++k) {
+    RGCN_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+    RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+  }
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  {
+    const char* e = getenv("RGCN_STREAMS");
+    c->use_aux = !(e && atoi(e) == 0);
+  }
   RGCN_HIP(c, hipEventCreate(&c->t0));
   RGCN_HIP(c, hipEventCreate(&c->t1));
 
@@ -230,8 +275,8 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   if (c->kind == RGCN_KIND_BLOCK) {
     RGCN_TRY(dmalloc(c, &c->msgbuf, (M ? M : 1) * d, false));
     const size_t per_rel = (size_t)c->sd * c->sd * c->nb;
-    const size_t dw = ((M + c->chunk - 1) / c->chunk + 2 * R) * per_rel;
-    if (dw > slab) slab = dw;
+    c->slab_dw_floats = ((M + c->chunk - 1) / c->chunk + 2 * R) * per_rel;
+    RGCN_TRY(dmalloc(c, &c->slab_dw, c->slab_dw_floats, false));
   } else {
     const size_t zc = 2 * (size_t)c->B * d;
     RGCN_TRY(dmalloc(c, &c->msgbuf, V * zc));
@@ -246,7 +291,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     if ((size_t)p.count > stage) stage = (size_t)p.count;
   c->stage_floats = stage;
   RGCN_TRY(dmalloc(c, &c->stage, stage, false));
-  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 63) / 64) * d));
+  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 31) / 32) * d));
   RGCN_TRY(dmalloc(c, &c->zeros, 64));
   RGCN_TRY(graph_alloc(c));
   {
@@ -295,16 +340,21 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const float* Hin = c->H[l - 1];
   const int d = c->d, V = c->V;
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
-  // self-loop: S = H . W_self  (rows of this rank's shard)
-  RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                    c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
   if (c->kind == RGCN_KIND_BLOCK) {
-    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    {   // the relational messages (HBM-bound) run beside the self-loop GEMM (MFMA-bound)
+      StreamScope side(c, 0);
+      RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+      RGCN_TRY(long_row_reduce(c, c->msgbuf));
+    }
+    // self-loop: S = H . W_self  (rows of this rank's shard)
+    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                      c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+    RGCN_TRY(stream_join(c, 0));
     CombineArgs a;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
-    a.row_ptr = c->g.row_ptr; a.gate = nullptr; a.V = V; a.d = d;
+    a.row_ptr = c->g.row_ptr; a.row_end = c->g.row_end; a.gate = nullptr; a.V = V; a.d = d;
     a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
     a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
@@ -347,17 +397,33 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   const int rows = hi - lo;
   LayerBufs& lb = c->layers[l];
-  // dW_self = H_in^T . dS   (K = rows of this shard, split over K)
-  RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                    c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  if (c->kind != RGCN_KIND_BLOCK) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
+  {   // the relational gradient kernels (HBM-bound) run on a side stream beside the two self-loop
+      // GEMMs (MFMA-bound); the GEMMs themselves stay back-to-back on the main stream -- running two
+      // MFMA-bound grids concurrently only interleaves them (measured: slower than serial).
+    StreamScope side(c, 0);
+    RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
+    RGCN_TRY(long_row_reduce(c, c->msgbuf));
+  }
+  static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
+  if (sched == 0) {
+    StreamScope side(c, 1);
+    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  }
   // G = dS . W_self^T
   RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                     c->self_buf + (size_t)lo * d, d, 1));
-  if (c->kind != RGCN_KIND_BLOCK) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
-  RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
+  if (sched == 2) {   // dW_self on side stream 1, but only after the dH GEMM has drained
+    StreamScope side(c, 1);
+    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  }
+  RGCN_TRY(stream_join(c, 0));
   const double Mmsg = 2.0 * c->g.E / c->world;
   CombineArgs a;
   a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr; a.row_ptr = c->g.row_ptr;
+  a.row_end = c->g.row_end;
   a.V = V; a.d = d; a.relu = 0; a.row_lo = lo; a.row_hi = hi;
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
@@ -370,6 +436,15 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
     RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
   }
+  if (sched == 1) {
+    // dW_self = H_in^T . dS   (K = rows of this shard, split over K); after the combine so that the
+    // next layer's message kernel (side stream) has a GEMM to hide under as well
+    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  }
+  // the dW_self GEMM must be done before the next layer overwrites its dS operand / the caller
+  // all-reduces gwself
+  RGCN_TRY(stream_join(c, 1));
   return RGCN_OK;
 }
 
@@ -380,7 +455,7 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
   float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
   if (c->world > 1) {
     CombineArgs a;
-    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr;
+    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.row_end = nullptr;
     a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = 0; a.row_hi = c->V;
     a.drop = make_drop(c, l, false);
     a.drop2 = d2;

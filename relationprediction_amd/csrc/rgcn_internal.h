@@ -54,6 +54,10 @@ __host__ __device__ inline uint32_t drop_bits(uint64_t seed, uint32_t layer, uin
 
 enum DropMode { DROP_NONE = 0, DROP_RNG = 1, DROP_MASK = 2 };
 
+// Rows of the incidence CSR with more slots than this are pre-reduced by a whole workgroup
+// (k_long_row_reduce) so that the one-wave-group-per-row combine never walks a hub serially.
+constexpr int kLongRow = 32;
+
 struct DropSpec {
   int32_t mode;         // DropMode
   uint32_t layer;       // 1..L
@@ -116,6 +120,11 @@ struct GraphBufs {
   int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, cnt, relcnt)
   size_t counters_bytes = 0;
   int32_t* row_ptr = nullptr;   // [V+1]
+  int32_t* row_end = nullptr;   // [V]  end of the slots combine() must read: row_ptr[v+1], or
+                                //      row_ptr[v]+1 for a long row (pre-reduced into its first slot)
+  int32_t* long_rows = nullptr; // compacted list of rows with more than kLongRow slots
+  int32_t* nlong = nullptr;     // device counter (lives in the zero-initialised counter block)
+  int32_t long_cap = 0;
   int32_t* rel_ptr = nullptr;   // [2R+1]
   int32_t* chunk_ptr = nullptr; // [2R+1]
   int32_t* cum_in = nullptr;    // [V+1]  (tf_as_executed)
@@ -140,7 +149,11 @@ struct rgcn_ctx {
   int V = 0, R = 0, d = 0, L = 0, nb = 0, sd = 0, kind = 0, B = 0;
   int rank = 0, world = 1;
   int row_lo = 0, row_hi = 0;   // self-loop row shard of this rank
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;           // stream launches go to (main stream unless a StreamScope is active)
+  hipStream_t main_stream = nullptr;
+  hipStream_t aux[2] = {nullptr, nullptr};  // side streams for independent kernels of one layer
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool use_aux = true;
   std::string err;
 
   std::vector<rgcn::Param> params;
@@ -154,8 +167,11 @@ struct rgcn_ctx {
   float* dsbuf[2] = {nullptr, nullptr};  // dS_l ping-pong
   float* msgbuf = nullptr;               // Y / Z : [2*maxE, d]  (BLOCK)   or Z [V, 2B*d] (BASIS)
   float* msgbuf2 = nullptr;              // BASIS: dZ [V, 2B*d]
-  float* slab = nullptr;                 // split-K / dW partial slabs
+  float* slab = nullptr;                 // split-K partial slabs of the GEMM
   size_t slab_floats = 0;
+  float* slab_dw = nullptr;              // per-chunk dW slabs of the block-diagonal backward
+  size_t slab_dw_floats = 0;
+  void* sort_tmp2 = nullptr;             // second radix-sort workspace (relation sort on a side stream)
   float* stage = nullptr;                // host<->device staging for layout conversion
   size_t stage_floats = 0;
   uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
@@ -187,6 +203,17 @@ struct rgcn_ctx {
 };
 
 namespace rgcn {
+
+// Runs the launches inside its scope on side stream k, ordered after everything already queued on
+// the main stream (fork); join() makes the main stream wait for that side stream again.
+struct StreamScope {
+  rgcn_ctx* c;
+  hipStream_t saved;
+  bool active;
+  StreamScope(rgcn_ctx* ctx, int k);
+  ~StreamScope();
+};
+rgcn_status stream_join(rgcn_ctx* c, int k);
 
 // Brackets a launch with events when profiling is on.
 struct ProfScope {
@@ -229,6 +256,7 @@ struct CombineArgs {
   const float* base;     // optional [V,d] (valid for rows in [row_lo,row_hi))
   const float* msg;      // optional message rows [slots,d]; summed per CSR row
   const int32_t* row_ptr;
+  const int32_t* row_end; // per-row end of the slots to read (GraphBufs::row_end)
   const float* gate;     // optional: result *= (gate > 0)
   int32_t V, d;
   int32_t relu;
@@ -237,6 +265,8 @@ struct CombineArgs {
   DropSpec drop2;        // applied to out2
 };
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
+// sums the slots of every long row into the row's first slot (in place)
+rgcn_status long_row_reduce(rgcn_ctx* c, float* msg);
 rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
 rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds);
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols);

@@ -31,14 +31,14 @@ print(json.dumps(out))
 if __name__ == "__main__":
     flops = 2.0 * 14541 * 500 * 500
     for swz in (1,):
-        for var in (0, 2, 8, 9, 10):
-            env = dict(os.environ, RGCN_GEMM_VARIANT=str(var), RGCN_GEMM_SWIZZLE=str(swz))
+        for var, abl in ((0, 0), (0, 1), (0, 2), (0, 4), (0, 8), (0, 9), (0, 11), (0, 15)):
+            env = dict(os.environ, RGCN_GEMM_VARIANT=str(var), RGCN_GEMM_SWIZZLE=str(swz), RGCN_GEMM_ABLATE=str(abl))
             r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
             if r.returncode != 0:
                 print("variant", var, "swizzle", swz, "FAILED", r.stderr[-500:])
                 continue
             o = json.loads(r.stdout.strip().splitlines()[-1])
-            line = "variant %d swizzle %d err %.1e :" % (var, swz, o.pop("err"))
+            line = "variant %d ablate %d err %.1e :" % (var, abl, o.pop("err"))
             for k, ms in o.items():
                 line += "  %s %.1f us (%.0f TF)" % (k, ms * 1e3, flops / (ms * 1e-3) / 1e12)
             print(line, flush=True)
