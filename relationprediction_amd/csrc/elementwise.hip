@@ -73,6 +73,12 @@ __global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] *= drop_scale(a.drop, off + k);
     }
+    if (a.add != nullptr) {
+      float ad[VEC];
+      vload<VEC>(a.add + off, ad);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += ad[k];
+    }
     const float* mp = a.msg + (size_t)cidx * VEC;
     int s = beg;
     for (; s + 4 <= end; s += 4) {   // 4 independent 16-B loads in flight per lane
@@ -295,7 +301,7 @@ DropSpec make_drop(const rgcn_ctx* c, int layer, bool active) {
 
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes) {
   if (a.V <= 0) return RGCN_OK;
-  const bool vec4 = (a.d % 4 == 0) && aligned16(a.out) && aligned16(a.base) && aligned16(a.msg) &&
+  const bool vec4 = (a.d % 4 == 0) && aligned16(a.out) && aligned16(a.base) && aligned16(a.msg) && aligned16(a.add) &&
                     aligned16(a.gate) && aligned16(a.out2);
   const int nvec = vec4 ? a.d / 4 : a.d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);

@@ -156,7 +156,8 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
                              const int32_t* __restrict__ pos, const int32_t* __restrict__ indeg,
                              const int32_t* __restrict__ outdeg, const int32_t* __restrict__ cum_in,
                              const int32_t* __restrict__ cum_out, int32_t* m_src, int32_t* m_dst,
-                             int32_t* m_dslot, int32_t* m_sslot, float* m_norm) {
+                             int32_t* m_dslot, int32_t* m_sslot, float* m_norm, int32_t* d_msg,
+                             int32_t* s_msg) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 2 * E) return;
   if (j >= rel_ptr[2 * R]) return;    // beyond the owned messages
@@ -180,8 +181,11 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
   m_src[j] = src;
   m_dst[j] = dst;
   m_norm[j] = norm;
-  m_dslot[j] = pos[m];
-  m_sslot[j] = pos[fwd ? m + E : m - E];
+  const int ds = pos[m], ss = pos[fwd ? m + E : m - E];
+  m_dslot[j] = ds;
+  m_sslot[j] = ss;
+  d_msg[ds] = j;
+  s_msg[ss] = j;
 }
 
 int bits_for(uint32_t max_value) {
@@ -232,6 +236,8 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   RGCN_TRY(dalloc(c, &g.m_dslot, M));
   RGCN_TRY(dalloc(c, &g.m_sslot, M));
   RGCN_TRY(dalloc(c, &g.m_norm, M));
+  RGCN_TRY(dalloc(c, &g.d_msg, M));
+  RGCN_TRY(dalloc(c, &g.s_msg, M));
   RGCN_TRY(dalloc(c, &g.owner, (size_t)c->R));
   RGCN_TRY(dalloc(c, &g.errflag, 1));
   RGCN_HIP(c, hipMemsetAsync(g.owner, 0, sizeof(int32_t) * (size_t)(c->R ? c->R : 1), c->stream));
@@ -257,7 +263,7 @@ void graph_free(rgcn_ctx* c) {
   GraphBufs& g = c->g;
   void* ptrs[] = {g.long_rows, g.row_end, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
-                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.owner, g.errflag, g.sort_tmp};
+                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg, g.owner, g.errflag, g.sort_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g = GraphBufs();
@@ -322,7 +328,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
       ProfScope ps(c, "prep_build_msgs", 12.0 * E + 28.0 * M, 0);
       hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
                          c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
-                         g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm);
+                         g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg);
     }
   }
   RGCN_HIP(c, hipGetLastError());

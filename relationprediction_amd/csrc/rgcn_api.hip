@@ -167,7 +167,8 @@ static void free_all(rgcn_ctx* c) {
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
-  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->slab_dw); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own); F(c->zeros);
+  F(c->msgbuf); F(c->msgbuf2); F(c->slab); F(c->slab_dw); F(c->aggbuf);
+  for (float* z : c->zsave) F(z); F(c->stage); F(c->masks); F(c->colsum_part); F(c->dcodes_own); F(c->zeros);
   for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->t0) (void)hipEventDestroy(c->t0);
@@ -279,10 +280,14 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     RGCN_TRY(dmalloc(c, &c->slab_dw, c->slab_dw_floats, false));
   } else {
     const size_t zc = 2 * (size_t)c->B * d;
-    RGCN_TRY(dmalloc(c, &c->msgbuf, V * zc));
     RGCN_TRY(dmalloc(c, &c->msgbuf2, V * zc));
-    const size_t s2 = 64 * zc * d;
+    RGCN_TRY(dmalloc(c, &c->aggbuf, Vd));
+    c->zsave.assign(c->L + 1, nullptr);
+    for (int l = 1; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->zsave[l], V * zc));
+    const size_t s2 = 16 * zc * d;
     if (s2 > slab) slab = s2;
+    c->slab_dw_floats = ((M + c->chunk - 1) / c->chunk + 2 * R) * (size_t)c->B;
+    RGCN_TRY(dmalloc(c, &c->slab_dw, c->slab_dw_floats, false));
   }
   c->slab_floats = slab;
   RGCN_TRY(dmalloc(c, &c->slab, slab));
@@ -353,6 +358,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
                       c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     RGCN_TRY(stream_join(c, 0));
     CombineArgs a;
+    a.add = nullptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
     a.row_ptr = c->g.row_ptr; a.row_end = c->g.row_end; a.gate = nullptr; a.V = V; a.d = d;
     a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
@@ -361,7 +367,22 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     a.drop2 = make_drop(c, l, false);
     RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
   } else {
-    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
+    // aggregate first: Z[v,(dir,b),:] = sum n C[rel,b] H[src];  pre = dropout(H.W_self) + Z.W'
+    const int zc = 2 * c->B * d;
+    RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
+    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                      c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+    RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, zc, c->zsave[l], zc, c->layers[l].wrel, d,
+                      c->aggbuf, d, 1));
+    CombineArgs a;
+    a.add = c->aggbuf;
+    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr;
+    a.row_end = nullptr; a.gate = nullptr; a.V = V; a.d = d;
+    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
+    a.row_lo = lo; a.row_hi = hi;
+    a.drop = make_drop(c, l, true);
+    a.drop2 = make_drop(c, l, false);
+    RGCN_TRY(combine(c, "combine_fwd", a, 12.0 * V * d));
   }
   return RGCN_OK;
 }
@@ -397,33 +418,13 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   const int rows = hi - lo;
   LayerBufs& lb = c->layers[l];
-  if (c->kind != RGCN_KIND_BLOCK) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "basis path not built in this revision");
-  {   // the relational gradient kernels (HBM-bound) run on a side stream beside the two self-loop
-      // GEMMs (MFMA-bound); the GEMMs themselves stay back-to-back on the main stream -- running two
-      // MFMA-bound grids concurrently only interleaves them (measured: slower than serial).
-    StreamScope side(c, 0);
-    RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
-    RGCN_TRY(long_row_reduce(c, c->msgbuf));
-  }
-  static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
-  if (sched == 0) {
-    StreamScope side(c, 1);
-    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
-  }
-  // G = dS . W_self^T
-  RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                    c->self_buf + (size_t)lo * d, d, 1));
-  if (sched == 2) {   // dW_self on side stream 1, but only after the dH GEMM has drained
-    StreamScope side(c, 1);
-    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
-  }
-  RGCN_TRY(stream_join(c, 0));
   const double Mmsg = 2.0 * c->g.E / c->world;
+  static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
+
+  // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
   CombineArgs a;
-  a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr; a.row_ptr = c->g.row_ptr;
-  a.row_end = c->g.row_end;
+  a.add = nullptr;
+  a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr; a.row_end = nullptr;
   a.V = V; a.d = d; a.relu = 0; a.row_lo = lo; a.row_hi = hi;
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
@@ -431,16 +432,51 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
     a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
     a.gate = Hin;
-    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
   } else {
     a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
   }
-  if (sched == 1) {
-    // dW_self = H_in^T . dS   (K = rows of this shard, split over K); after the combine so that the
-    // next layer's message kernel (side stream) has a GEMM to hide under as well
+
+  if (c->kind == RGCN_KIND_BLOCK) {
+    {   // the relational gradient kernels (HBM-bound) run on a side stream beside the self-loop GEMMs
+        // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).
+      StreamScope side(c, 0);
+      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
+      RGCN_TRY(long_row_reduce(c, c->msgbuf));
+    }
+    if (sched == 0) {
+      StreamScope side(c, 1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+    }
+    // G = dS . W_self^T
+    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                      c->self_buf + (size_t)lo * d, d, 1));
+    if (sched == 2) {   // dW_self = H_in^T . dS on side stream 1, queued behind the dH GEMM
+      StreamScope side(c, 1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+    }
+    RGCN_TRY(stream_join(c, 0));
+    a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
+    a.row_ptr = c->g.row_ptr;
+    a.row_end = c->g.row_end;
+    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
+    if (sched == 1)
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+  } else {
+    const int zc = 2 * c->B * d;
+    // self-loop gradients
     RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
                       c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                      c->self_buf + (size_t)lo * d, d, 1));
+    // dZ = D . W'^T   ([V,d] x [d,2B.d]);   dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
+    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, zc, d, c->bwd_D, d, lb.wrel, d, c->msgbuf2, zc, 1));
+    RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
+                      auto_split_k(zc, d, V)));
+    RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
+    RGCN_TRY(basis_backward_gather(c, l, c->msgbuf2, a, true));
   }
   // the dW_self GEMM must be done before the next layer overwrites its dS operand / the caller
   // all-reduces gwself
@@ -455,6 +491,7 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
   float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
   if (c->world > 1) {
     CombineArgs a;
+    a.add = nullptr;
     a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.row_end = nullptr;
     a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = 0; a.row_hi = c->V;
     a.drop = make_drop(c, l, false);
@@ -494,6 +531,8 @@ static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev) {
     if (c->world > 1) {
       RGCN_TRY(comm_allreduce(c, c->exch, (int64_t)c->V * c->d));
       RGCN_TRY(comm_allreduce(c, c->layers[l].gwself, (int64_t)c->d * c->d));
+      if (c->kind == RGCN_KIND_BASIS)   // the basis tensors are replicated: their gradient is a sum over shards
+        RGCN_TRY(comm_allreduce(c, c->layers[l].grel, (int64_t)2 * c->B * c->d * c->d));
     }
     RGCN_TRY(bwd_layer_finish(c, l));
   }

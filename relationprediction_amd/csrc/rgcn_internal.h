@@ -134,6 +134,7 @@ struct GraphBufs {
   int32_t* pos = nullptr;       // [2maxE] incidence -> CSR slot
   // relation-sorted message list (SoA, [2maxE] each)
   int32_t *m_src = nullptr, *m_dst = nullptr, *m_dslot = nullptr, *m_sslot = nullptr;
+  int32_t *d_msg = nullptr, *s_msg = nullptr;   // inverse maps: destination- / source-order slot -> message
   float* m_norm = nullptr;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -167,6 +168,8 @@ struct rgcn_ctx {
   float* dsbuf[2] = {nullptr, nullptr};  // dS_l ping-pong
   float* msgbuf = nullptr;               // Y / Z : [2*maxE, d]  (BLOCK)   or Z [V, 2B*d] (BASIS)
   float* msgbuf2 = nullptr;              // BASIS: dZ [V, 2B*d]
+  std::vector<float*> zsave;             // BASIS: Z of every layer, kept for dW' = Z^T.D
+  float* aggbuf = nullptr;               // BASIS: Z.W' product [V,d]
   float* slab = nullptr;                 // split-K partial slabs of the GEMM
   size_t slab_floats = 0;
   float* slab_dw = nullptr;              // per-chunk dW slabs of the block-diagonal backward
@@ -245,7 +248,10 @@ rgcn_status block_from_device_layout(rgcn_ctx* c, const float* src, float* host_
 
 // ---- basis.hip
 rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z);
-rgcn_status basis_backward_sparse(rgcn_ctx* c, int layer, const float* Hin, const float* dZ, float* Zt);
+struct CombineArgs;
+rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const CombineArgs& ca,
+                                  bool with_messages);
+rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* dZ);
 rgcn_status basis_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst);
 rgcn_status basis_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev);
 
@@ -253,7 +259,8 @@ rgcn_status basis_from_device_layout(rgcn_ctx* c, const float* src, float* host_
 struct CombineArgs {
   float* out;            // primary output [V,d]
   float* out2;           // optional: out * dropout(drop2)
-  const float* base;     // optional [V,d] (valid for rows in [row_lo,row_hi))
+  const float* base;     // optional [V,d] (valid for rows in [row_lo,row_hi)); dropout `drop` applies
+  const float* add;      // optional [V,d] added as is (basis: the Z.W' product)
   const float* msg;      // optional message rows [slots,d]; summed per CSR row
   const int32_t* row_ptr;
   const int32_t* row_end; // per-row end of the slots to read (GraphBufs::row_end)

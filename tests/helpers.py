@@ -59,22 +59,40 @@ def probe(arr, n=256, seed=0):
                 sum=np.float64(a.astype(np.float64).sum()), idx=idx.astype(np.int64), val=a[idx].copy())
 
 
-def check_probe(arr, pr, rel=2e-4, name=""):
+# Gradient comparisons tolerate ISOLATED relu-gate flips: a pre-activation within fp32 rounding of 0
+# can land on different sides in two correct fp32 implementations (different summation order), which
+# moves a handful of gradient entries by O(1e-3 * scale).  The oracle itself shows this against its own
+# float64 rerun (W_self1 of fb237_basis_B2_L2: max 1.3e-3 relative, while the l2 error stays ~1e-6).
+# So: the bulk must agree to `rel` (l2 / 98 % of sampled entries), no entry may be off by more than
+# `spike` x scale.
+def check_probe(arr, pr, rel=2e-4, spike=5e-3, name=""):
     a = np.asarray(arr, dtype=np.float32).ravel()
     scale = max(float(np.abs(pr["val"]).max()), 1e-12)
-    err = float(np.abs(a[pr["idx"]] - pr["val"]).max())
-    assert err <= rel * scale + 1e-7, "%s: sampled entries differ: err %.3e scale %.3e" % (name, err, scale)
+    diff = np.abs(a[pr["idx"]] - pr["val"])
+    err = float(diff.max())
+    assert err <= spike * scale + 1e-7, "%s: sampled entry off by %.3e (scale %.3e)" % (name, err, scale)
+    frac_bad = float((diff > rel * scale + 1e-7).mean())
+    assert frac_bad <= 0.02, "%s: %.1f%% of sampled entries differ by more than %.0e x scale" % (
+        name, 100 * frac_bad, rel)
     l2 = float(np.sqrt(np.sum(a.astype(np.float64) ** 2)))
     assert abs(l2 - float(pr["l2"])) <= rel * max(float(pr["l2"]), 1e-12) + 1e-7, "%s: l2 norm differs" % name
 
 
-def assert_close(got, ref, rel=2e-4, abs_tol=1e-7, name=""):
+def assert_close(got, ref, rel=2e-4, abs_tol=1e-7, spike=5e-3, name=""):
     got = np.asarray(got)
     ref = np.asarray(ref)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     if ref.size == 0:
         return
     assert np.isfinite(got).all(), "%s: non-finite values" % name
-    scale = float(np.abs(ref).max())
-    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max())
-    assert err <= rel * scale + abs_tol, "%s: max err %.3e vs scale %.3e (rel %.1e)" % (name, err, scale, rel)
+    g64, r64 = got.astype(np.float64), ref.astype(np.float64)
+    scale = float(np.abs(r64).max())
+    diff = np.abs(g64 - r64)
+    err = float(diff.max())
+    assert err <= spike * scale + abs_tol, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+    l2 = float(np.sqrt((diff ** 2).sum()))
+    l2ref = float(np.sqrt((r64 ** 2).sum()))
+    assert l2 <= rel * l2ref + abs_tol * np.sqrt(ref.size), "%s: l2 err %.3e vs %.3e (rel %.1e)" % (
+        name, l2, l2ref, rel)
+    frac_bad = float((diff > rel * scale + abs_tol).mean())
+    assert frac_bad <= 0.01, "%s: %.2f%% of entries differ by more than %.0e x scale" % (name, 100 * frac_bad, rel)

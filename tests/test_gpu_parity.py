@@ -1,7 +1,8 @@
 """GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
 same seeded inputs.  Tolerance: forward activations within 1e-4 absolute (BASELINE.json north_star,
-fp32) -- enforced as max|err| <= 1e-4; gradients within 2e-4 of the tensor's max magnitude (fp32
-summation order differs from the oracle's; SURVEY.md 8c "TF numerics to mirror").
+fp32) -- enforced as max|err| <= 1e-4 on every element; gradients: l2 error and >= 99 % of the entries
+within 2e-4 of the tensor's scale, no entry off by more than 5e-3 x scale (isolated relu-gate flips,
+see tests/helpers.py; fp32 summation order differs from the oracle's).  GEMM alone: 1e-5.
 """
 import os
 
@@ -72,11 +73,11 @@ def test_gemm_forms(native, M, N, K, form):
         else:
             got = eng.debug_gemm(np.ascontiguousarray(A.T), B, trans_a=True)
             got2 = eng.debug_gemm(np.ascontiguousarray(A.T), B, trans_a=True, split_k=3)
-            assert_close(got2, ref, rel=1e-5, name="TN split 3")
+            assert_close(got2, ref, rel=1e-5, spike=1e-5, name="TN split 3")
     finally:
         eng.close()
     # asymmetric random operands: a swapped row/col mapping cannot pass
-    assert_close(got, ref, rel=1e-5, name=form)
+    assert_close(got, ref, rel=1e-5, spike=1e-5, name=form)
 
 
 # ------------------------------------------------------------------ graph preparation
@@ -125,6 +126,43 @@ def test_block_encoder_matches_oracle(native, V, R, d, L, nb, E, norm):
                                         dropout_masks=masks, norm_mode=norm)
     acts, grads = run_engine(native, V, R, d, L, "block", nb, params, triples, masks, dcodes, norm=norm)
     compare(acts, grads, oacts, ograds, tag="block")
+
+
+BASIS_CASES = [
+    # V, R, d, L, B, E
+    (16, 9, 10, 1, 5, 43),       # BASELINE config 1 shape family (Toy-sized, 1 layer)
+    (16, 9, 12, 2, 2, 43),
+    (50, 7, 20, 2, 3, 200),
+    (40, 11, 9, 2, 2, 120),      # d % 4 != 0 (scalar paths)
+    (20, 4, 8, 2, 1, 1),         # E = 1, B = 1
+    (25, 6, 12, 2, 2, 0),        # empty graph
+    (30, 5, 16, 3, 9, 90),       # B > 8: two register passes
+    (300, 40, 500, 2, 2, 900),   # real width d = 500, B = 2
+]
+
+
+@pytest.mark.parametrize("V,R,d,L,B,E", BASIS_CASES)
+@pytest.mark.parametrize("norm", ["intended", "tf_as_executed"])
+def test_basis_encoder_matches_oracle(native, V, R, d, L, B, E, norm):
+    params, triples, masks, dcodes = make_case(V, R, d, L, "basis", B, E, seed=V + E + 1)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "basis", dcodes, keep_prob=0.8,
+                                        dropout_masks=masks, norm_mode=norm)
+    acts, grads = run_engine(native, V, R, d, L, "basis", B, params, triples, masks, dcodes, norm=norm)
+    compare(acts, grads, oacts, ograds, tag="basis")
+
+
+def test_basis_hub_and_test_mode(native):
+    V, R, d, L, B = 60, 12, 20, 2, 3
+    params, _, masks, dcodes = make_case(V, R, d, L, "basis", B, 10, seed=19)
+    rng = np.random.RandomState(4)
+    hub = np.stack([rng.randint(0, 30, 250), rng.randint(0, 3, 250), np.full(250, 7)], 1)
+    dup = np.tile(np.array([[1, 2, 3]]), (17, 1))
+    triples = np.concatenate([hub, dup, np.stack([np.arange(10), np.full(10, 4), np.arange(10)], 1)]).astype(np.int32)
+    oacts = oracle.encoder_forward(params, triples, V, L, "basis", mode="test")
+    ograds = oracle.encoder_backward(params, triples, V, L, "basis", oacts, dcodes, mode="test")
+    acts, grads = run_engine(native, V, R, d, L, "basis", B, params, triples, None, dcodes, train=False)
+    compare(acts, grads, oacts, ograds, tag="basis-hub")
+    assert not grads["C_f1"][5:].any()
 
 
 def test_block_edge_structures(native):
@@ -238,9 +276,10 @@ def probes_for(expected, case, norm):
     return {n: {f: expected[pre + n + "/" + f] for f in ("l2", "sum", "idx", "val")} for n in names}
 
 
-@pytest.mark.parametrize("case", ["toy_block_small", "toy_block_L2", "fb237_block_L2"])
+@pytest.mark.parametrize("case", ["toy_block_small", "toy_block_L2", "fb237_block_L2", "toy_basis_L1",
+                                  "fb237_basis_B2_L2"])
 @pytest.mark.parametrize("norm", ["intended", "tf_as_executed"])
-def test_block_golden(native, expected, case, norm):
+def test_golden(native, expected, case, norm):
     c = helpers.golden_inputs(case)
     acts, grads = run_engine(native, c["V"], c["R"], c["d"], c["L"], c["kind"], c["nb"], c["params"],
                              c["triples"], c["masks"], c["dcodes"], norm=norm)
@@ -281,15 +320,15 @@ def test_full_graph_inference_shape(native):
 
 # ------------------------------------------------------------------ relation sharding on one GPU
 @pytest.mark.parametrize("world", [2, 4])
-def test_relation_sharding_with_host_exchange(native, world):
+def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4):
     """world ranks as separate contexts on ONE device; the all-reduce is done by the test through
     read_buffer/write_buffer (the collective's test double).  Result must equal the unsharded run."""
     V, R, d, L, nb, E = 90, 10, 20, 2, 4, 600
-    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=12)
-    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
+    params, triples, masks, dcodes = make_case(V, R, d, L, kind, nb, E, seed=12)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, kind, dcodes, dropout_masks=masks)
     from relationprediction_amd.sharding import lpt_partition
     owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
-    engs = [native.Engine(V, R, d, L, "block", nb, max_edges=E, rank=r, world=world) for r in range(world)]
+    engs = [native.Engine(V, R, d, L, kind, nb, max_edges=E, rank=r, world=world) for r in range(world)]
     try:
         for e in engs:
             e.set_params(params)
@@ -323,15 +362,24 @@ def test_relation_sharding_with_host_exchange(native, world):
             g = e.get_grads()
             for name in ["W_emb", "b_emb", "W_self1", "W_self2"]:
                 assert_close(g[name], ograds[name], rel=2e-4, name="rank%d %s" % (r, name))
-            for name in ["W_f1", "W_b1", "W_f2", "W_b2"]:       # only the owner holds a relation's gradient
+            per_rel = ["W_f1", "W_b1", "W_f2", "W_b2"] if kind == "block" else ["C_f1", "C_b1", "C_f2", "C_b2"]
+            for name in per_rel:       # only the owner holds a relation's gradient
                 mine = owner == r
                 assert_close(g[name][mine], ograds[name][mine], rel=2e-4, name="rank%d %s" % (r, name))
                 assert not g[name][~mine].any()
+        if kind == "basis":            # replicated basis tensors: the gradient is the sum over shards
+            for name in ["W_f1", "W_b1", "W_f2", "W_b2"]:
+                tot = sum(e.get_grad(name) for e in engs)
+                assert_close(tot, ograds[name], rel=2e-4, name="sum over ranks " + name)
         for b in dbufs:
             b.free()
     finally:
         for e in engs:
             e.close()
+
+
+def test_relation_sharding_basis(native):
+    test_relation_sharding_with_host_exchange(native, 2, kind="basis", nb=3)
 
 
 def test_rccl_single_rank_communicator(native):
