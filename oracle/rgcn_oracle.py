@@ -381,7 +381,9 @@ def distmult_loss_and_grads(codes, W_relation, X, Y, reg_param=0.01):
     loss = per.mean(dtype=np.float64)
     reg = reg_param * (np.mean(e1.astype(np.float64) ** 2) + np.mean(rr.astype(np.float64) ** 2)
                        + np.mean(e2.astype(np.float64) ** 2))
-    dx = ((1.0 / (1.0 + np.exp(-x))) - z) / N                 # d mean(xent)/dx = sigmoid(x) - z
+    ex = np.exp(-np.abs(x))
+    sig = np.where(x >= 0, 1.0 / (1.0 + ex), ex / (1.0 + ex))
+    dx = (sig - z) / N                                         # d mean(xent)/dx = sigmoid(x) - z
     dcol = X.shape[0] * codes.shape[1]
     g_e1 = dx[:, None] * (rr * e2) + reg_param * 2.0 * e1 / dcol
     g_r = dx[:, None] * (e1 * e2) + reg_param * 2.0 * rr / dcol

@@ -1,0 +1,91 @@
+"""EncoderRuntime: binds a chain of reference-shaped plugin components to ONE HIP engine context.
+
+The reference builds a TF graph by recursing through `get_all_codes` (message_gcn.py:39,58) and runs
+it in `session.run`.  Here the same recursion is collapsed: the first `get_all_codes` of a step makes
+the engine run the whole encoder stack (input layer + L graph-convolution layers) and every component
+then reads "its" activation.  The runtime lives on the graph `Representation` at the bottom of the chain.
+"""
+import numpy as np
+
+from . import _native
+
+
+class EncoderRuntime(object):
+    def __init__(self, layers, affine, representation):
+        """layers: MessageGcn components bottom -> top."""
+        self.layers = layers
+        self.affine = affine
+        self.representation = representation
+        kinds = {type(l).KIND for l in layers}
+        if len(kinds) != 1:
+            raise NotImplementedError("mixed graph-convolution layer types in one encoder")
+        self.kind = kinds.pop()
+        top = layers[-1]
+        for i, l in enumerate(layers):
+            if l.use_nonlinearity != (i < len(layers) - 1):
+                raise NotImplementedError("only 'relu on all but the last layer' stacks are supported "
+                                          "(model_builder.py:275)")
+            if l.onehot_input:
+                raise NotImplementedError("onehot_input graph-convolution layers (UseInputTransform=No)")
+        s = top.settings
+        self.V, self.R = top.entity_count, top.relation_count
+        self.d = int(top.shape[1])
+        norm = s['IncidenceNormalization'] if 'IncidenceNormalization' in s else 'intended'
+        device = int(s['Device']) if 'Device' in s else 0
+        max_edges = max(int(top.edge_count), 1)
+        if 'GraphBatchSize' in s:
+            max_edges = max(max_edges, int(s['GraphBatchSize']))
+        self.engine = _native.Engine(self.V, self.R, self.d, len(layers), self.kind, top.n_coefficients,
+                                     keep_prob=top.dropout_keep_probability, norm_mode=norm,
+                                     max_edges=max_edges, device=device)
+        self._state = None        # (graph version, mode) of the activations held by the engine
+        self._graph_version = None
+        self.weights_version = 0
+        self._fwd_weights_version = -1
+        # move the weights into the engine (names follow rgcn_param_info)
+        affine.W.bind(*self._accessors("W_emb"))
+        affine.b.bind(*self._accessors("b_emb"))
+        for i, l in enumerate(layers, start=1):
+            l.layer_index = i
+            for var, base in l.engine_variables():
+                var.bind(*self._accessors("%s%d" % (base, i)))
+
+    def _accessors(self, name):
+        eng = self.engine
+
+        def getter():
+            return eng.get_param(name)
+
+        def setter(value):
+            eng.set_param(name, value)
+            self.weights_version += 1
+
+        return getter, setter
+
+    def forward(self, mode):
+        ph = self.representation.X
+        if ph.value is None:
+            raise RuntimeError("graph_edges was not fed")
+        if self._graph_version != ph.version:
+            self.engine.set_graph(ph.value)
+            self._graph_version = ph.version
+            self._state = None
+        key = (ph.version, mode, self.weights_version)
+        if self._state != key:
+            train = mode == 'train'
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) if train else 0
+            self.engine.forward(train=train, seed=seed)
+            self._state = key
+        return self
+
+    def activation(self, layer):
+        return self.engine.activation(layer)
+
+    def backward(self, dcodes):
+        if self._state is None or self._state[1] != 'train':
+            raise RuntimeError("backward() needs a train-mode forward pass on the current graph")
+        self.engine.backward(dcodes)
+        return self
+
+    def grad(self, name):
+        return self.engine.get_grad(name)

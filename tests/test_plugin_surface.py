@@ -1,0 +1,134 @@
+"""The drop-in boundary on the Python side: settings format, file formats, the plugin chain that
+model_builder assembles, weight-list order and initialiser stream -- all checkable without a GPU."""
+import numpy as np
+import pytest
+
+import oracle
+from relationprediction_amd.common import io, model_builder, settings_reader
+
+BLOCK_EXP = """[Encoder]
+\tName=gcn_basis
+\tDropoutKeepProbability=0.8
+\tInternalEncoderDimension=20
+\tNumberOfBasisFunctions=4
+\tNumberOfLayers=2
+\tUseInputTransform=Yes
+\tUseOutputTransform=No
+\tAddDiagonal=No
+\tDiagonalCoefficients=No
+\tSkipConnections=None
+\tStoreEdgeData=No
+\tRandomInput=No
+\tPartiallyRandomInput=No
+\tConcatenation=Yes
+
+[Decoder]
+\tName=bilinear-diag
+\tRegularizationParameter=0.01
+
+[Shared]
+\tCodeDimension=20
+
+[Optimizer]
+\tMaxGradientNorm=1
+\tReportTrainLossEvery=100
+
+\t[EarlyStopping]
+\t\tCheckEvery=2000
+\t\tBurninPhaseDuration=6000
+
+\t[Algorithm]
+\t\tName=Adam
+\t\tlearning_rate=0.01
+
+[General]
+\tNegativeSampleRate=10
+\tGraphSplitSize=0.5
+\tExperimentName=models/GcnBlock
+
+[Evaluation]
+\tMetric=MRR
+"""
+
+
+def load_settings(tmp_path, text=BLOCK_EXP, V=16, R=9, E=43):
+    p = tmp_path / "x.exp"
+    p.write_text(text)
+    s = settings_reader.read(str(p))
+    enc, dec, shared, gen = s['Encoder'], s['Decoder'], s['Shared'], s['General']
+    gen.put('EntityCount', V)            # code/train.py:76-78
+    gen.put('RelationCount', R)
+    gen.put('EdgeCount', E)
+    enc.merge(shared); enc.merge(gen)    # code/train.py:80-83
+    dec.merge(shared); dec.merge(gen)
+    return s, enc, dec
+
+
+def test_settings_reader_format(tmp_path):
+    s, enc, dec = load_settings(tmp_path)
+    assert list(s) == ['Encoder', 'Decoder', 'Shared', 'Optimizer', 'General', 'Evaluation']
+    assert s['Optimizer']['EarlyStopping']['BurninPhaseDuration'] == '6000'      # nested block
+    assert s['Optimizer']['Algorithm']['learning_rate'] == '0.01'                # values stay strings
+    assert 'MaxGradientNorm' in s['Optimizer'] and 'Nope' not in s['Optimizer']
+    assert enc['CodeDimension'] == '20' and enc['EntityCount'] == 16             # merge + put
+    assert 'GraphBatchSize' not in s['General']
+
+
+def test_io_formats(tmp_path):
+    (tmp_path / "entities.dict").write_text("0\tTove\n1\tGyrid\n2\tCnut\n")
+    (tmp_path / "relations.dict").write_text("0\tKingOf\n1\tWifeOf\n")
+    (tmp_path / "train.txt").write_text("Tove\tWifeOf\tCnut\nCnut\tKingOf\tGyrid\n")
+    ent = str(tmp_path / "entities.dict")
+    rel = str(tmp_path / "relations.dict")
+    assert io.read_dictionary(ent) == {0: "Tove", 1: "Gyrid", 2: "Cnut"}
+    assert io.read_dictionary(rel, id_lookup=False) == {"KingOf": 0, "WifeOf": 1}
+    assert io.read_triplets_as_list(str(tmp_path / "train.txt"), ent, rel) == [[0, 1, 2], [2, 0, 1]]
+
+
+@pytest.mark.parametrize("concat", ["Yes", "No"])
+def test_chain_structure_weight_order_and_init_stream(tmp_path, concat):
+    text = BLOCK_EXP.replace("Concatenation=Yes", "Concatenation=" + concat)
+    s, enc, dec = load_settings(tmp_path, text)
+    triples = np.zeros((43, 3), dtype=int)
+    model = model_builder.build_decoder(model_builder.build_encoder(enc, triples), dec)
+    kind = "block" if concat == "Yes" else "basis"
+    names = [type(c).__name__ for c in _chain(model)]
+    layer = "ConcatGcn" if concat == "Yes" else "BasisGcn"
+    assert names == ["BilinearDiag", "RelationEmbedding", layer, layer, "AffineTransform", "Representation"]
+    assert model.needs_graph()
+    np.random.seed(7)
+    model.initialize_train()
+    # placeholders in the reference's feed order: graph_edges, X, Y (optimize.py:81-88)
+    assert [p.name for p in model.get_train_input_variables()] == ["graph_edges", "X", "Y"]
+    assert [p.name for p in model.get_test_input_variables()] == ["graph_edges", "X"]
+    weights = model.get_weights()
+    per_layer = ["W_forward", "W_backward", "W_self", "b"] if kind == "block" else \
+        ["W_forward", "W_backward", "C_forward", "C_backward", "W_self", "b"]
+    assert [w.name for w in weights] == ["W_emb", "b_emb"] + per_layer * 2 + ["W_relation"]
+    # same numpy stream consumption as the reference's creation order (outermost component first)
+    ref = oracle.init_params(16, 9, 20, 2, kind, 4, rng=np.random.RandomState(7))
+    for w, name in zip(weights, oracle.weight_names(kind, 2)):
+        np.testing.assert_array_equal(w.value(), ref[name], err_msg=name)
+    # use_nonlinearity: every layer but the last (model_builder.py:275)
+    gcn = [c for c in _chain(model) if type(c).__name__ == layer]
+    assert [g.use_nonlinearity for g in gcn] == [False, True]          # chain order is top -> bottom
+
+
+def _chain(model):
+    c = model
+    while c is not None:
+        yield c
+        c = c.next_component
+
+
+def test_out_of_scope_variants_fail_loudly(tmp_path):
+    for key in ("UseOutputTransform", "AddDiagonal", "StoreEdgeData"):
+        s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace(key + "=No", key + "=Yes"))
+        with pytest.raises(NotImplementedError):
+            model_builder.build_encoder(enc, np.zeros((3, 3), dtype=int))
+    s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace("Name=gcn_basis", "Name=embedding"))
+    with pytest.raises(NotImplementedError):
+        model_builder.build_encoder(enc, np.zeros((3, 3), dtype=int))
+    s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace("Name=bilinear-diag", "Name=complex"))
+    with pytest.raises(NotImplementedError):
+        model_builder.build_decoder(None, dec)
