@@ -61,6 +61,8 @@ def main():
     import numpy as np
 
     dist = None
+    if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
+        import torch  # noqa: F401  (test knob: exercise the torch-first load order on one GPU)
     if world > 1:
         # control plane only (rendezvous of the RCCL id, barriers); the data path is our own RCCL
         # communicator on the engine's stream.  torch is imported BEFORE librgcn.so so that one HIP

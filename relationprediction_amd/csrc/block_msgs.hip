@@ -253,6 +253,13 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
     }));
     RGCN_HIP(c, hipGetLastError());
   }
+  return RGCN_OK;
+}
+
+// dW[rel] = ordered sum of the relation's chunk slabs written by block_msg_backward
+rgcn_status block_dw_reduce(rgcn_ctx* c, int layer) {
+  const int per_rel = c->sd * c->sd * c->nb;
+  const int R2 = 2 * c->R;
   {
     // also correct for E == 0: chunk_ptr is all zeros => every relation gets a zero gradient
     const int64_t n = (int64_t)R2 * per_rel;

@@ -41,6 +41,7 @@ struct GemmArgs {
   int k_per_split;   // multiple of BK
   int tiles_m, tiles_n, splits;
   int swizzle;       // XCD-aware workgroup remap
+  int vecC;          // 16-byte row-contiguous stores legal (aligned C, ldc % 4 == 0, N % 4 == 0)
   int ablate;        // timing experiments only (tools/gemm_sweep.py): 1 no in-loop global loads, 2 no barrier, 4 no stores
 };
 
@@ -133,7 +134,10 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
   constexpr int TA = A_KC ? BM * CF::LDK : BK * BM;
   constexpr int TB = B_KC ? BN * CF::LDK : BK * BN;
   constexpr int PA = BM * BK / 4 / NT, PB = BN * BK / 4 / NT;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (TA + TB)];
+  constexpr int EPI_LD = BN + 4;                       // row stride of the epilogue staging tile
+  constexpr int EPI = 64 * EPI_LD;                     // 64 output rows at a time
+  constexpr int LDS_FLOATS = 2 * (TA + TB) > EPI ? 2 * (TA + TB) : EPI;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   // ---- workgroup -> (k-slab, row tile, column tile); XCD-aware so that neighbours share an L2
   int wg = blockIdx.x;
@@ -209,6 +213,38 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
 
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
   float* C = g.C + (size_t)z * g.M * g.ldc;   // slab z (ldc == N for slabs)
+  if (g.vecC) {
+    // stage 64 output rows at a time through LDS so that every global store is a full 16-byte,
+    // row-contiguous access (8x fewer store instructions than the per-register dword stores)
+#pragma unroll
+    for (int pass = 0; pass < BM / 64; ++pass) {
+      if (wm / 64 == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (wm % 64) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+              lds[row * EPI_LD + wn + 32 * j + li] = acc[i][j][r];
+            }
+      }
+      __syncthreads();
+      constexpr int C4 = BN / 4;
+#pragma unroll
+      for (int q = 0; q < 64 * C4 / NT; ++q) {
+        const int f = threadIdx.x + NT * q;
+        const int row = f / C4, c4 = f % C4;
+        const int grow = m0 + 64 * pass + row, gcol = n0 + 4 * c4;
+        if (grow < g.M && gcol < g.N) {
+          const float4 v = *reinterpret_cast<const float4*>(lds + row * EPI_LD + 4 * c4);
+          *reinterpret_cast<float4*>(C + (size_t)grow * g.ldc + gcol) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -247,6 +283,7 @@ void launch_v(rgcn_ctx* c, bool a_kc, bool b_kc, GemmArgs& g) {
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
   g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(CF::NT);
+  static_assert((64 * CF::BN / 4) % CF::NT == 0 && CF::TM * 32 <= 64, "epilogue staging geometry");
   if (a_kc && !b_kc) hipLaunchKernelGGL((k_gemm_f32<true, false, VEC, CF>), grid, block, 0, c->stream, g);
   else if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm_f32<true, true, VEC, CF>), grid, block, 0, c->stream, g);
   else hipLaunchKernelGGL((k_gemm_f32<false, false, VEC, CF>), grid, block, 0, c->stream, g);
@@ -270,7 +307,7 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   if (a_kc == false && b_kc == true) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "gemm TT form not instantiated");
   static const int variant = env_int("RGCN_GEMM_VARIANT", 0);     // tuning knob (tools/gemm_sweep.py)
   static const int swizzle = env_int("RGCN_GEMM_SWIZZLE", 1);
-  const int bk = (variant == 1 || variant == 3 || variant == 5) ? 32 : 16;
+  const int bk = 16;
   GemmArgs g;
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
   const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N);
@@ -292,19 +329,12 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   } else {
     g.C = C; g.ldc = ldc;
   }
+  static const int epi = env_int("RGCN_GEMM_EPILOGUE", 1);
+  g.vecC = (epi && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
   {
     ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * N * K);
     switch (variant) {
-      case 1: launch<Cfg<128, 128, 32, 2, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 2: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;  // == default
-      case 3: launch<Cfg<128, 128, 32, 4, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 4: launch<Cfg<64, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 5: launch<Cfg<64, 128, 32, 2, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 6: launch<Cfg<128, 64, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 7: launch<Cfg<64, 64, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
       case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
-      case 9: launch<Cfg<256, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;
-      case 10: launch<Cfg<128, 256, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
       case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
       default: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;
     }

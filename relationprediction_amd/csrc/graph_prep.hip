@@ -28,26 +28,6 @@ namespace {
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 16;
 
-__global__ void k_hist(const int32_t* __restrict__ tri, int E, int V, int R,
-                       const int32_t* __restrict__ owner, int rank, int32_t* indeg, int32_t* outdeg,
-                       int32_t* cnt, int32_t* relcnt, int32_t* errflag) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
-  if ((unsigned)s >= (unsigned)V || (unsigned)o >= (unsigned)V || (unsigned)r >= (unsigned)R) {
-    atomicOr(errflag, 1);
-    return;
-  }
-  atomicAdd(&indeg[o], 1);
-  atomicAdd(&outdeg[s], 1);
-  if (owner[r] == rank) {
-    atomicAdd(&cnt[o], 1);
-    atomicAdd(&cnt[s], 1);
-    atomicAdd(&relcnt[r], 1);
-    atomicAdd(&relcnt[R + r], 1);
-  }
-}
-
 struct ScanJob {
   const int32_t* in;
   int32_t* out;     // n + 1 entries
@@ -105,12 +85,94 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
   if (tid == 0) job.out[job.n] = carry_s;
 }
 
-// row_end + compacted list of long rows (order of the list is irrelevant: rows are independent)
-__global__ void k_rows(const int32_t* __restrict__ row_ptr, int V, int32_t* row_end, int32_t* long_rows,
-                       int32_t* nlong, int cap) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  const int beg = row_ptr[v], end = row_ptr[v + 1];
+// One thread per incidence: sort keys for the two sorts; the first E threads also count the GLOBAL
+// degrees (all fed edges, owned or not) and validate the ids.
+__global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
+                       const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
+                       uint32_t* keyr, int32_t* valr, int32_t* indeg, int32_t* outdeg, int32_t* errflag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * E) return;
+  const bool fwd = i < E;
+  const int e = fwd ? i : i - E;
+  int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
+  bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
+  if (fwd) {
+    if (ok) {
+      atomicAdd(&indeg[o], 1);
+      atomicAdd(&outdeg[s], 1);
+    } else {
+      atomicOr(errflag, 1);
+    }
+  }
+  bool owned = ok && owner[r] == rank;
+  keyv[i] = owned ? (uint32_t)(fwd ? o : s) : (uint32_t)V;   // incidence i sits at this vertex
+  valv[i] = i;
+  keyr[i] = owned ? (uint32_t)(fwd ? r : R + r) : (uint32_t)(2 * R);
+  valr[i] = i;
+}
+
+__device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_t x) {
+  int lo = 0, hi = n;   // first index with a[i] >= x
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// CSR offsets straight from the sorted keys (no counting atomics, no scan):
+//   blocks 1..: row_ptr[v] = lower_bound(vertex keys, v); row_end / long-row list alongside;
+//   block 0  : rel_ptr[r] = lower_bound(relation keys, r) and the exclusive scan of the per-relation
+//              chunk counts (2R <= a few thousand entries: one workgroup).
+__global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv_s,
+                                               const uint32_t* __restrict__ keyr_s, int M, int V, int R2,
+                                               int chunk, int32_t* row_ptr, int32_t* row_end,
+                                               int32_t* long_rows, int32_t* nlong, int cap, int32_t* rel_ptr,
+                                               int32_t* chunk_ptr) {
+  if (blockIdx.x == 0) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base <= R2; base += 1024) {
+      const int r = base + tid;
+      int lo = 0, nchunks = 0;
+      if (r <= R2) {
+        lo = lower_bound_u32(keyr_s, M, (uint32_t)r);
+        rel_ptr[r] = lo;
+        if (r < R2) {
+          const int hi = lower_bound_u32(keyr_s, M, (uint32_t)(r + 1));
+          nchunks = (hi - lo + chunk - 1) / chunk;
+        }
+      }
+      int incl = nchunks;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) wsum[wid] = incl;
+      __syncthreads();
+      int wbase = 0, total = 0;
+      for (int w = 0; w < 16; ++w) {
+        if (w < wid) wbase += wsum[w];
+        total += wsum[w];
+      }
+      const int carry = carry_s;
+      if (r <= R2) chunk_ptr[r] = carry + wbase + incl - nchunks;
+      __syncthreads();
+      if (tid == 0) carry_s = carry + total;
+      __syncthreads();
+    }
+    return;
+  }
+  const int v = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (v > V) return;
+  const int beg = lower_bound_u32(keyv_s, M, (uint32_t)v);
+  row_ptr[v] = beg;
+  if (v == V) return;
+  const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1));
   if (end - beg > kLongRow) {
     const int i = atomicAdd(nlong, 1);
     if (i < cap) long_rows[i] = v;
@@ -118,22 +180,6 @@ __global__ void k_rows(const int32_t* __restrict__ row_ptr, int V, int32_t* row_
   } else {
     row_end[v] = end;
   }
-}
-
-__global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
-                       const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
-                       uint32_t* keyr, int32_t* valr) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * E) return;
-  const bool fwd = i < E;
-  const int e = fwd ? i : i - E;
-  int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
-  bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
-  bool owned = ok && owner[r] == rank;
-  keyv[i] = owned ? (uint32_t)(fwd ? o : s) : (uint32_t)V;   // incidence i sits at this vertex
-  valv[i] = i;
-  keyr[i] = owned ? (uint32_t)(fwd ? r : R + r) : (uint32_t)(2 * R);
-  valr[i] = i;
 }
 
 __global__ void k_pos(const int32_t* __restrict__ permv, int n, int32_t* pos) {
@@ -206,13 +252,11 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   GraphBufs& g = c->g;
   const size_t V = c->V, R2 = 2 * (size_t)c->R, M = 2 * (size_t)c->cfg.max_edges;
   RGCN_TRY(dalloc(c, &g.triples, 3 * (size_t)c->cfg.max_edges));
-  g.counters_bytes = (3 * V + R2 + 1) * sizeof(int32_t);
-  RGCN_TRY(dalloc(c, &g.counters, 3 * V + R2 + 1));
+  g.counters_bytes = (2 * V + 1) * sizeof(int32_t);
+  RGCN_TRY(dalloc(c, &g.counters, 2 * V + 1));
   g.indeg = g.counters;
   g.outdeg = g.counters + V;
-  g.cnt = g.counters + 2 * V;
-  g.relcnt = g.counters + 3 * V;
-  g.nlong = g.counters + 3 * V + R2;
+  g.nlong = g.counters + 2 * V;
   g.long_cap = (int32_t)(M / kLongRow + 1);
   RGCN_TRY(dalloc(c, &g.long_rows, (size_t)g.long_cap));
   RGCN_TRY(dalloc(c, &g.row_end, V));
@@ -272,6 +316,7 @@ void graph_free(rgcn_ctx* c) {
 rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   GraphBufs& g = c->g;
   const int E = (int)E64, V = c->V, R = c->R;
+  const int M = 2 * E;
   g.cur = tri;
   g.E = E;
   g.ready = false;
@@ -279,32 +324,10 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
   const int T = 256;
   if (E > 0) {
-    ProfScope ps(c, "prep_hist", 12.0 * E, 0);
-    hipLaunchKernelGGL(k_hist, dim3((E + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
-                       c->rank, g.indeg, g.outdeg, g.cnt, g.relcnt, g.errflag);
-  }
-  {
-    ScanJobs jobs;
-    jobs.j[0] = {g.cnt, g.row_ptr, V, 0};
-    jobs.j[1] = {g.relcnt, g.rel_ptr, 2 * R, 0};
-    jobs.j[2] = {g.relcnt, g.chunk_ptr, 2 * R, c->chunk};
-    jobs.j[3] = {g.indeg, g.cum_in, V, 0};
-    jobs.j[4] = {g.outdeg, g.cum_out, V, 0};
-    const int njobs = (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) ? 5 : 3;
-    ProfScope ps(c, "prep_scan", 8.0 * (V + 4 * R), 0);
-    hipLaunchKernelGGL(k_exscan, dim3(njobs), dim3(kScanThreads), 0, c->stream, jobs);
-  }
-  {
-    ProfScope ps(c, "prep_rows", 8.0 * V, 0);
-    hipLaunchKernelGGL(k_rows, dim3((V + T - 1) / T), dim3(T), 0, c->stream, g.row_ptr, V, g.row_end,
-                       g.long_rows, g.nlong, g.long_cap);
-  }
-  if (E > 0) {
-    const int M = 2 * E;
     {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
-                         c->rank, g.keyv, g.valv, g.keyr, g.valr);
+                         c->rank, g.keyv, g.valv, g.keyr, g.valr, g.indeg, g.outdeg, g.errflag);
     }
     {   // the two sorts are independent: relation sort on a side stream
       StreamScope side(c, 0);
@@ -324,12 +347,26 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
       hipLaunchKernelGGL(k_pos, dim3((M + T - 1) / T), dim3(T), 0, c->stream, g.permv, M, g.pos);
     }
     RGCN_TRY(stream_join(c, 0));
-    {
-      ProfScope ps(c, "prep_build_msgs", 12.0 * E + 28.0 * M, 0);
-      hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
-                         c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
-                         g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg);
-    }
+  }
+  {
+    ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
+    hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
+                       M, V, 2 * R, c->chunk, g.row_ptr, g.row_end, g.long_rows, g.nlong, g.long_cap,
+                       g.rel_ptr, g.chunk_ptr);
+  }
+  if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
+    ScanJobs jobs;
+    jobs.j[0] = {g.indeg, g.cum_in, V, 0};
+    jobs.j[1] = {g.outdeg, g.cum_out, V, 0};
+    jobs.j[2] = jobs.j[3] = jobs.j[4] = jobs.j[0];
+    ProfScope ps(c, "prep_scan", 16.0 * V, 0);
+    hipLaunchKernelGGL(k_exscan, dim3(2), dim3(kScanThreads), 0, c->stream, jobs);
+  }
+  if (E > 0) {
+    ProfScope ps(c, "prep_build_msgs", 12.0 * E + 36.0 * M, 0);
+    hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
+                       c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
+                       g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg);
   }
   RGCN_HIP(c, hipGetLastError());
   g.ready = true;

@@ -216,9 +216,17 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_HIP(c, hipSetDevice(f.device));
   RGCN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->main_stream = c->stream;
-  for (int k = 0; k < 2; ++k) {
-    RGCN_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-    RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+  {
+    // side streams get the highest priority: their short HBM-bound kernels should claim wave slots
+    // ahead of the long MFMA-bound grid they run beside
+    int prio_lo = 0, prio_hi = 0;
+    RGCN_HIP(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const char* e = getenv("RGCN_STREAM_PRIO");
+    const bool use_prio = !(e && atoi(e) == 0);
+    for (int k = 0; k < 2; ++k) {
+      RGCN_HIP(c, hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, use_prio ? prio_hi : prio_lo));
+      RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+    }
   }
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   {
@@ -442,6 +450,10 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       StreamScope side(c, 0);
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
       RGCN_TRY(long_row_reduce(c, c->msgbuf));
+      // the combine below needs only the message rows: mark the join point here, then let the
+      // per-relation dW reduction trail behind on the side stream
+      if (side.active) RGCN_HIP(c, hipEventRecord(c->ev_join[0], c->aux[0]));
+      RGCN_TRY(block_dw_reduce(c, l));
     }
     if (sched == 0) {
       StreamScope side(c, 1);
@@ -456,7 +468,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
                         c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
     }
-    RGCN_TRY(stream_join(c, 0));
+    if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
     a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
     a.row_ptr = c->g.row_ptr;
     a.row_end = c->g.row_end;
@@ -507,7 +519,8 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
 static rgcn_status bwd_end(rgcn_ctx* c) {
   if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
   // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
-  return column_sum(c, c->g_emb, c->gb_emb, c->V, c->d);
+  RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
+  return stream_join(c, 0);   // trailing per-relation dW reductions
 }
 
 static rgcn_status forward_all(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks) {

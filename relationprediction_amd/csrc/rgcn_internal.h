@@ -115,9 +115,7 @@ struct GraphBufs {
   int64_t E = 0;
   int32_t* indeg = nullptr;     // [V]
   int32_t* outdeg = nullptr;    // [V]
-  int32_t* cnt = nullptr;       // [V]   owned incidences per vertex
-  int32_t* relcnt = nullptr;    // [2R]  owned messages per directed relation
-  int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, cnt, relcnt)
+  int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, nlong)
   size_t counters_bytes = 0;
   int32_t* row_ptr = nullptr;   // [V+1]
   int32_t* row_end = nullptr;   // [V]  end of the slots combine() must read: row_ptr[v+1], or
@@ -243,6 +241,7 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
 rgcn_status block_geometry(rgcn_ctx* c);
 rgcn_status block_msg_forward(rgcn_ctx* c, int layer, const float* Hin, float* Ybuf);
 rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const float* D, float* Zbuf);
+rgcn_status block_dw_reduce(rgcn_ctx* c, int layer);
 rgcn_status block_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst, int R);
 rgcn_status block_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev, int R);
 
