@@ -49,36 +49,134 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
   }
 }
 
-// TPR lanes per row, 256 / TPR rows per workgroup.
+// Epilogue shared by the row kernels: gate (relu'), relu, store, dropout-scaled second copy.
+template <int VEC>
+__device__ __forceinline__ void combine_epilogue(const CombineArgs& a, size_t off, float (&acc)[VEC]) {
+  if (a.gate != nullptr) {
+    float gt[VEC];
+    vload<VEC>(a.gate + off, gt);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = gt[k] > 0.0f ? acc[k] : 0.0f;
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = fmaxf(acc[k], 0.0f);
+  }
+  vstore<VEC>(a.out + off, acc);
+  if (a.out2 != nullptr) {
+    float o2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_scale(a.drop2, off + k);
+    vstore<VEC>(a.out2 + off, o2);
+  }
+}
+
+// dropout(base) + add for one vector of one row
+template <int VEC>
+__device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, size_t off, float (&acc)[VEC]) {
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+  if (a.base != nullptr && v >= a.row_lo && v < a.row_hi) {
+    vload<VEC>(a.base + off, acc);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] *= drop_scale(a.drop, off + k);
+  }
+  if (a.add != nullptr) {
+    float ad[VEC];
+    vload<VEC>(a.add + off, ad);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += ad[k];
+  }
+}
+
+constexpr int kCombineThreads = 1024;
+constexpr int kLongBlocks = 64;     // extra workgroups of the combine grid that walk the long-row list
+
+// Workgroups [0, nb_rows): TPR lanes per row, 1024 / TPR rows per workgroup, rows with more than
+// kLongRow slots are skipped.  Workgroups [nb_rows, nb_rows + kLongBlocks): one LONG row at a time
+// with 1024 / 128 = 8 slot-lanes x 128 column lanes (16 loads in flight per lane), LDS combines the
+// 8 partial sums in a fixed order -- a hub never serialises one wave group, and no extra launch.
 template <int VEC, int TPR>
-__global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
-  const int rows_per_block = 256 / TPR;
-  const int v = blockIdx.x * rows_per_block + threadIdx.x / TPR;
+__global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int n_long_blocks) {
+  const int nvec = a.d / VEC;
+  // the long-row workgroups come FIRST in the grid so that they start at t = 0 and finish under the
+  // cover of the ordinary rows
+  if ((int)blockIdx.x < n_long_blocks) {
+    __shared__ float red[8][128 * VEC];
+    if (a.msg == nullptr) return;
+    const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int n = *a.nlong;
+    for (int b = blockIdx.x; b < n; b += n_long_blocks) {
+      const int v = a.long_rows[b];
+      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      for (int c0 = 0; c0 < nvec; c0 += 128) {
+        const int cidx = c0 + cl;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        if (cidx < nvec) {
+          const float* mp = a.msg + (size_t)cidx * VEC;
+          int s = beg + sl;
+          for (; s + 8 * 15 < end; s += 8 * 16) {
+            float m[16][VEC];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * a.d, m[u]);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
+          }
+          for (; s + 24 < end; s += 32) {
+            float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
+            vload<VEC>(mp + (size_t)(s + 0) * a.d, m0);
+            vload<VEC>(mp + (size_t)(s + 8) * a.d, m1);
+            vload<VEC>(mp + (size_t)(s + 16) * a.d, m2);
+            vload<VEC>(mp + (size_t)(s + 24) * a.d, m3);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
+          }
+          for (; s < end; s += 8) {
+            float m0[VEC];
+            vload<VEC>(mp + (size_t)s * a.d, m0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+        __syncthreads();
+        if (sl == 0 && cidx < nvec) {
+          const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+          float tot[VEC];
+          combine_prologue<VEC>(a, v, off, tot);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            float t = red[0][cl * VEC + k];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
+            tot[k] += t;
+          }
+          combine_epilogue<VEC>(a, off, tot);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  const int rows_per_block = kCombineThreads / TPR;
+  const int v = ((int)blockIdx.x - n_long_blocks) * rows_per_block + threadIdx.x / TPR;
   if (v >= a.V) return;
   const int lane = threadIdx.x % TPR;
-  const int nvec = a.d / VEC;
   int beg = 0, end = 0;
   if (a.msg != nullptr) {
     beg = a.row_ptr[v];
-    end = a.row_end[v];
+    end = a.row_ptr[v + 1];
+    if (end - beg > kLongRow) return;       // handled by a long-row workgroup of this same launch
   }
-  const bool base_valid = a.base != nullptr && v >= a.row_lo && v < a.row_hi;
   for (int cidx = lane; cidx < nvec; cidx += TPR) {
     const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
     float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    if (base_valid) {
-      vload<VEC>(a.base + off, acc);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] *= drop_scale(a.drop, off + k);
-    }
-    if (a.add != nullptr) {
-      float ad[VEC];
-      vload<VEC>(a.add + off, ad);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] += ad[k];
-    }
+    combine_prologue<VEC>(a, v, off, acc);
     const float* mp = a.msg + (size_t)cidx * VEC;
     int s = beg;
     for (; s + 4 <= end; s += 4) {   // 4 independent 16-B loads in flight per lane
@@ -96,89 +194,7 @@ __global__ void __launch_bounds__(256) k_combine(CombineArgs a) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
     }
-    if (a.gate != nullptr) {
-      float gt[VEC];
-      vload<VEC>(a.gate + off, gt);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = gt[k] > 0.0f ? acc[k] : 0.0f;
-    }
-    if (a.relu) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = fmaxf(acc[k], 0.0f);
-    }
-    vstore<VEC>(a.out + off, acc);
-    if (a.out2 != nullptr) {
-      float o2[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_scale(a.drop2, off + k);
-      vstore<VEC>(a.out2 + off, o2);
-    }
-  }
-}
-
-// One workgroup per long row: 8 slot-lanes x 128 column-lanes; each slot-lane strides over the row's
-// slots with 4 independent loads in flight, LDS combines the 8 partial sums in a fixed order, and
-// the result replaces the row's first slot (combine() then reads exactly one slot for this row).
-template <int VEC>
-__global__ void __launch_bounds__(1024) k_long_row_reduce(float* __restrict__ msg,
-                                                          const int32_t* __restrict__ row_ptr,
-                                                          const int32_t* __restrict__ long_rows,
-                                                          const int32_t* __restrict__ nlong, int d) {
-  __shared__ float red[8][128 * VEC];
-  const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
-  const int nvec = d / VEC;
-  const int n = *nlong;
-  for (int b = blockIdx.x; b < n; b += gridDim.x) {   // few long rows: a small persistent grid
-  const int v = long_rows[b];
-  const int beg = row_ptr[v], end = row_ptr[v + 1];
-  for (int c0 = 0; c0 < nvec; c0 += 128) {
-    const int cidx = c0 + cl;
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    if (cidx < nvec) {
-      const float* mp = msg + (size_t)cidx * VEC;
-      int s = beg + sl;
-      for (; s + 8 * 15 < end; s += 8 * 16) {   // 16 independent loads in flight per lane
-        float m[16][VEC];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * d, m[u]);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
-      }
-      for (; s + 24 < end; s += 32) {
-        float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
-        vload<VEC>(mp + (size_t)(s + 0) * d, m0);
-        vload<VEC>(mp + (size_t)(s + 8) * d, m1);
-        vload<VEC>(mp + (size_t)(s + 16) * d, m2);
-        vload<VEC>(mp + (size_t)(s + 24) * d, m3);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
-      }
-      for (; s < end; s += 8) {
-        float m0[VEC];
-        vload<VEC>(mp + (size_t)s * d, m0);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
-    __syncthreads();
-    if (sl == 0 && cidx < nvec) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        float t = red[0][cl * VEC + k];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
-        acc[k] = t;
-      }
-      vstore<VEC>(msg + (size_t)beg * d + (size_t)cidx * VEC, acc);
-    }
-    __syncthreads();
-  }
+    combine_epilogue<VEC>(a, off, acc);
   }
 }
 
@@ -305,11 +321,13 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double a
                     aligned16(a.gate) && aligned16(a.out2);
   const int nvec = vec4 ? a.d / 4 : a.d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-  const int rows_per_block = 256 / tpr;
-  dim3 grid((a.V + rows_per_block - 1) / rows_per_block), block(256);
+  const int rows_per_block = kCombineThreads / tpr;
+  const int nb_rows = (a.V + rows_per_block - 1) / rows_per_block;
+  const int n_long_blocks = a.msg != nullptr ? kLongBlocks : 0;
+  dim3 grid(nb_rows + n_long_blocks), block(kCombineThreads);
   ProfScope ps(c, tag, alg_bytes, 0);
 #define RGCN_LAUNCH_COMBINE(VEC, TPR) \
-  hipLaunchKernelGGL((k_combine<VEC, TPR>), grid, block, 0, c->stream, a)
+  hipLaunchKernelGGL((k_combine<VEC, TPR>), grid, block, 0, c->stream, a, n_long_blocks)
   if (vec4) {
     if (tpr == 64) RGCN_LAUNCH_COMBINE(4, 64);
     else if (tpr == 128) RGCN_LAUNCH_COMBINE(4, 128);
@@ -320,22 +338,6 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double a
     else RGCN_LAUNCH_COMBINE(1, 256);
   }
 #undef RGCN_LAUNCH_COMBINE
-  RGCN_HIP(c, hipGetLastError());
-  return RGCN_OK;
-}
-
-rgcn_status long_row_reduce(rgcn_ctx* c, float* msg) {
-  if (c->g.E == 0) return RGCN_OK;
-  int64_t blocks = 2 * c->g.E / kLongRow + 1;
-  if (blocks > c->g.long_cap) blocks = c->g.long_cap;
-  if (blocks > 128) blocks = 128;
-  ProfScope ps(c, "long_row_reduce", 0, 0);
-  if (c->d % 4 == 0 && aligned16(msg))
-    hipLaunchKernelGGL((k_long_row_reduce<4>), dim3((unsigned)blocks), dim3(1024), 0, c->stream, msg,
-                       c->g.row_ptr, c->g.long_rows, c->g.nlong, c->d);
-  else
-    hipLaunchKernelGGL((k_long_row_reduce<1>), dim3((unsigned)blocks), dim3(1024), 0, c->stream, msg,
-                       c->g.row_ptr, c->g.long_rows, c->g.nlong, c->d);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

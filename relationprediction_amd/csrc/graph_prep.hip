@@ -126,7 +126,7 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_
 //              chunk counts (2R <= a few thousand entries: one workgroup).
 __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv_s,
                                                const uint32_t* __restrict__ keyr_s, int M, int V, int R2,
-                                               int chunk, int32_t* row_ptr, int32_t* row_end,
+                                               int chunk, int32_t* row_ptr,
                                                int32_t* long_rows, int32_t* nlong, int cap, int32_t* rel_ptr,
                                                int32_t* chunk_ptr) {
   if (blockIdx.x == 0) {
@@ -176,9 +176,6 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   if (end - beg > kLongRow) {
     const int i = atomicAdd(nlong, 1);
     if (i < cap) long_rows[i] = v;
-    row_end[v] = beg + 1;
-  } else {
-    row_end[v] = end;
   }
 }
 
@@ -259,8 +256,6 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   g.nlong = g.counters + 2 * V;
   g.long_cap = (int32_t)(M / kLongRow + 1);
   RGCN_TRY(dalloc(c, &g.long_rows, (size_t)g.long_cap));
-  RGCN_TRY(dalloc(c, &g.row_end, V));
-  RGCN_HIP(c, hipMemsetAsync(g.row_end, 0, sizeof(int32_t) * V, c->stream));
   RGCN_TRY(dalloc(c, &g.row_ptr, V + 1));
   RGCN_TRY(dalloc(c, &g.rel_ptr, R2 + 1));
   RGCN_TRY(dalloc(c, &g.chunk_ptr, R2 + 1));
@@ -305,7 +300,7 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
 
 void graph_free(rgcn_ctx* c) {
   GraphBufs& g = c->g;
-  void* ptrs[] = {g.long_rows, g.row_end, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
+  void* ptrs[] = {g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg, g.owner, g.errflag, g.sort_tmp};
   for (void* p : ptrs)
@@ -351,7 +346,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
     hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
-                       M, V, 2 * R, c->chunk, g.row_ptr, g.row_end, g.long_rows, g.nlong, g.long_cap,
+                       M, V, 2 * R, c->chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
                        g.rel_ptr, g.chunk_ptr);
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {

@@ -359,7 +359,6 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     {   // the relational messages (HBM-bound) run beside the self-loop GEMM (MFMA-bound)
       StreamScope side(c, 0);
       RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-      RGCN_TRY(long_row_reduce(c, c->msgbuf));
     }
     // self-loop: S = H . W_self  (rows of this rank's shard)
     RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
@@ -368,7 +367,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     CombineArgs a;
     a.add = nullptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
-    a.row_ptr = c->g.row_ptr; a.row_end = c->g.row_end; a.gate = nullptr; a.V = V; a.d = d;
+    a.row_ptr = c->g.row_ptr; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong; a.gate = nullptr; a.V = V; a.d = d;
     a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
     a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
@@ -385,7 +384,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     CombineArgs a;
     a.add = c->aggbuf;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr;
-    a.row_end = nullptr; a.gate = nullptr; a.V = V; a.d = d;
+    a.long_rows = nullptr; a.nlong = nullptr; a.gate = nullptr; a.V = V; a.d = d;
     a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
     a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
@@ -432,7 +431,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
   CombineArgs a;
   a.add = nullptr;
-  a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr; a.row_end = nullptr;
+  a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
   a.V = V; a.d = d; a.relu = 0; a.row_lo = lo; a.row_hi = hi;
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
@@ -449,7 +448,6 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
         // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).
       StreamScope side(c, 0);
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
-      RGCN_TRY(long_row_reduce(c, c->msgbuf));
       // the combine below needs only the message rows: mark the join point here, then let the
       // per-relation dW reduction trail behind on the side stream
       if (side.active) RGCN_HIP(c, hipEventRecord(c->ev_join[0], c->aux[0]));
@@ -471,7 +469,8 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
     a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
     a.row_ptr = c->g.row_ptr;
-    a.row_end = c->g.row_end;
+    a.long_rows = c->g.long_rows;
+    a.nlong = c->g.nlong;
     RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
     if (sched == 1)
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
@@ -504,7 +503,7 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
   if (c->world > 1) {
     CombineArgs a;
     a.add = nullptr;
-    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.row_end = nullptr;
+    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
     a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = 0; a.row_hi = c->V;
     a.drop = make_drop(c, l, false);
     a.drop2 = d2;

@@ -118,8 +118,6 @@ struct GraphBufs {
   int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, nlong)
   size_t counters_bytes = 0;
   int32_t* row_ptr = nullptr;   // [V+1]
-  int32_t* row_end = nullptr;   // [V]  end of the slots combine() must read: row_ptr[v+1], or
-                                //      row_ptr[v]+1 for a long row (pre-reduced into its first slot)
   int32_t* long_rows = nullptr; // compacted list of rows with more than kLongRow slots
   int32_t* nlong = nullptr;     // device counter (lives in the zero-initialised counter block)
   int32_t long_cap = 0;
@@ -262,7 +260,8 @@ struct CombineArgs {
   const float* add;      // optional [V,d] added as is (basis: the Z.W' product)
   const float* msg;      // optional message rows [slots,d]; summed per CSR row
   const int32_t* row_ptr;
-  const int32_t* row_end; // per-row end of the slots to read (GraphBufs::row_end)
+  const int32_t* long_rows; // rows with more than kLongRow slots (GraphBufs::long_rows / nlong)
+  const int32_t* nlong;
   const float* gate;     // optional: result *= (gate > 0)
   int32_t V, d;
   int32_t relu;
@@ -271,8 +270,6 @@ struct CombineArgs {
   DropSpec drop2;        // applied to out2
 };
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
-// sums the slots of every long row into the row's first slot (in place)
-rgcn_status long_row_reduce(rgcn_ctx* c, float* msg);
 rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
 rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds);
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols);
