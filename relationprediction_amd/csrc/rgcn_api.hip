@@ -199,6 +199,10 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   c->rank = f.rank; c->world = f.world;
   if ((int64_t)c->V * c->d > (int64_t)1 << 31 || 2 * f.max_edges * (int64_t)c->d > ((int64_t)1 << 40))
     RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "problem too large for this build");
+  if (const char* e = getenv("RGCN_CHUNK")) {
+    const int v = atoi(e);
+    if (v >= 8 && v <= 4096) c->chunk = v;
+  }
   if (c->kind == RGCN_KIND_BLOCK) {
     c->nb = f.num_bases;
     if (c->d % c->nb != 0)

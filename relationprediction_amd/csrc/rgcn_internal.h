@@ -178,7 +178,7 @@ struct rgcn_ctx {
   float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
 
   rgcn::GraphBufs g;
-  int chunk = 96;                        // messages per relation chunk
+  int chunk = 48;                        // messages per relation chunk
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
 
   // forward/backward state
