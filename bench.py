@@ -79,6 +79,12 @@ def main():
     # data files with the reference's formats; /root/reference itself is not needed at run time)
     with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
         triples = np.ascontiguousarray(z[graph_name].astype(np.int32))
+        # a second minibatch of the same size so that consecutive steps see different graphs (as in
+        # training, where t_func samples a new one every step): steps alternate A, B, A, B ...
+        pool = z["fb237_valid_test"].astype(np.int32) if graph_name == "fb237_minibatch" else triples
+    rs = np.random.RandomState(7)
+    triples_b = np.ascontiguousarray(pool[rs.choice(pool.shape[0], size=triples.shape[0], replace=False)]) \
+        if pool.shape[0] >= triples.shape[0] else triples
     assert triples.shape[0] == E_g
     from relationprediction_amd.common.shared_functions import init_encoder_params
     params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
@@ -94,7 +100,10 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init(ids[0])
     tri_dev = eng.to_device(triples)
+    tri_dev_b = eng.to_device(triples_b)
     dc_dev = eng.to_device(dcodes)
+    graphs = [tri_dev, tri_dev_b]
+    pipeline = os.environ.get("RGCN_BENCH_PREFETCH", "1") != "0"
 
     def barrier():
         eng.sync()
@@ -102,8 +111,12 @@ def main():
             dist.barrier()
 
     def run(n, seed0):
+        # step i works on graph i % 2; while it runs, the next graph's CSR / message list is prepared
+        # on a side stream (what a training loop does with the next sampled minibatch)
         for i in range(n):
-            eng.step_device(tri_dev, E_g, dc_dev, train=True, seed=seed0 + i)
+            eng.step_device(graphs[i % 2], E_g, dc_dev, train=True, seed=seed0 + i)
+            if pipeline:
+                eng.prefetch_graph_device(graphs[(i + 1) % 2], E_g)
 
     run(args.warmup, 1000)
     barrier()
@@ -181,7 +194,10 @@ def main():
                     "reference-distribution random-init weights, synthetic upstream gradient",
             "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks": nb, "graph_edges": E_g,
-                       "step": "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
+                       "step": "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
+                               "two alternating minibatches, next graph's prep pipelined on a side stream"
+                               if pipeline else
+                               "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
                        "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
             "message_edges_per_s": round(2 * L * value, 1),
@@ -191,6 +207,7 @@ def main():
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
     tri_dev.free()
+    tri_dev_b.free()
     dc_dev.free()
     eng.close()
     if dist is not None:

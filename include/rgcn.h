@@ -164,6 +164,13 @@ rgcn_status rgcn_backward_device(rgcn_ctx* ctx, const float* dcodes_dev);
 rgcn_status rgcn_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges,
                              int32_t train, uint64_t dropout_seed, const float* dcodes_dev);
 
+/* Software pipelining across steps: prepare the graph structures of the NEXT minibatch (same work as
+ * rgcn_set_graph_device) on a side stream into a second buffer set while the step already queued
+ * keeps running.  A later rgcn_step_device with the same (pointer, num_edges) adopts them instead of
+ * rebuilding.  Call it AFTER queueing the current step.  The reference has no counterpart: its graph
+ * arrives through feed_dict at session.run (optimize.py:81-88). */
+rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev_next, int64_t num_edges);
+
 /* ---- relation sharding across GPUs (new: the reference is single-device) ------------
  * owner[r] in [0, world) assigns relation r's edges and W_f[r]/W_b[r] (BLOCK) or C_f[r]/C_b[r]
  * (BASIS) to one rank.  Degrees stay global.  Must be identical on all ranks. */

@@ -64,6 +64,7 @@ _SIGS = {
     "rgcn_backward": (C.c_int32, [_P, _P, C.c_int64]),
     "rgcn_backward_device": (C.c_int32, [_P, _P]),
     "rgcn_step_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_uint64, _P]),
+    "rgcn_prefetch_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
     "rgcn_set_relation_owner": (C.c_int32, [_P, _P, C.c_int32]),
     "rgcn_comm_unique_id": (C.c_int32, [_P]),
     "rgcn_comm_init": (C.c_int32, [_P, _P]),
@@ -306,6 +307,9 @@ class Engine:
     def step_device(self, triples_dev, num_edges, dcodes_dev, train=True, seed=0):
         self._check(self.lib.rgcn_step_device(self.ctx, triples_dev.ptr, int(num_edges), 1 if train else 0,
                                               C.c_uint64(seed), dcodes_dev.ptr))
+
+    def prefetch_graph_device(self, triples_dev, num_edges):
+        self._check(self.lib.rgcn_prefetch_graph_device(self.ctx, triples_dev.ptr, int(num_edges)))
 
     # -- phase API (sharding exchange points)
     def forward_begin(self, train=True, seed=0, masks=None):

@@ -245,7 +245,9 @@ rgcn_status dalloc(rgcn_ctx* c, T** p, size_t n) {
 
 }  // namespace
 
-rgcn_status graph_alloc(rgcn_ctx* c) {
+// `share`: a previously allocated set whose read-only / OR-only members (relation owner, error flag)
+// this set aliases.
+rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   GraphBufs& g = c->g;
   const size_t V = c->V, R2 = 2 * (size_t)c->R, M = 2 * (size_t)c->cfg.max_edges;
   RGCN_TRY(dalloc(c, &g.triples, 3 * (size_t)c->cfg.max_edges));
@@ -277,10 +279,17 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   RGCN_TRY(dalloc(c, &g.m_norm, M));
   RGCN_TRY(dalloc(c, &g.d_msg, M));
   RGCN_TRY(dalloc(c, &g.s_msg, M));
-  RGCN_TRY(dalloc(c, &g.owner, (size_t)c->R));
-  RGCN_TRY(dalloc(c, &g.errflag, 1));
-  RGCN_HIP(c, hipMemsetAsync(g.owner, 0, sizeof(int32_t) * (size_t)(c->R ? c->R : 1), c->stream));
-  RGCN_HIP(c, hipMemsetAsync(g.errflag, 0, sizeof(int32_t), c->stream));
+  if (share) {
+    g.owner = share->owner;
+    g.errflag = share->errflag;
+  } else {
+    RGCN_TRY(dalloc(c, &g.owner, (size_t)c->R));
+    RGCN_TRY(dalloc(c, &g.errflag, 1));
+    RGCN_HIP(c, hipMemsetAsync(g.owner, 0, sizeof(int32_t) * (size_t)(c->R ? c->R : 1), c->stream));
+    RGCN_HIP(c, hipMemsetAsync(g.errflag, 0, sizeof(int32_t), c->stream));
+  }
+  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_ready, hipEventDisableTiming));
+  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_free, hipEventDisableTiming));
   RGCN_HIP(c, hipMemsetAsync(g.row_ptr, 0, sizeof(int32_t) * (V + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.rel_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.chunk_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
@@ -294,18 +303,26 @@ rgcn_status graph_alloc(rgcn_ctx* c) {
   }
   g.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
   RGCN_HIP(c, hipMalloc(&g.sort_tmp, g.sort_tmp_bytes));
-  RGCN_HIP(c, hipMalloc(&c->sort_tmp2, g.sort_tmp_bytes));
+  RGCN_HIP(c, hipMalloc(&g.sort_tmp2, g.sort_tmp_bytes));
   return RGCN_OK;
 }
 
-void graph_free(rgcn_ctx* c) {
-  GraphBufs& g = c->g;
+static void graph_free_one(GraphBufs& g, bool owns_shared) {
+  if (!owns_shared) { g.owner = nullptr; g.errflag = nullptr; }
+  if (g.ev_ready) (void)hipEventDestroy(g.ev_ready);
+  if (g.ev_free) (void)hipEventDestroy(g.ev_free);
   void* ptrs[] = {g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
-                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg, g.owner, g.errflag, g.sort_tmp};
+                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg, g.owner, g.errflag, g.sort_tmp,
+                  g.sort_tmp2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g = GraphBufs();
+}
+
+void graph_free(rgcn_ctx* c) {
+  graph_free_one(c->g_alt, false);
+  graph_free_one(c->g, true);
 }
 
 rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
@@ -315,6 +332,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   g.cur = tri;
   g.E = E;
   g.ready = false;
+  g.pf_valid = false;
   c->fwd_done = false;
   RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
   const int T = 256;
@@ -328,7 +346,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
       StreamScope side(c, 0);
       ProfScope ps(c, "prep_sort_relation", 16.0 * M, 0);
       size_t tb = g.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(c->sort_tmp2, tb, g.keyr, g.keyr_s, g.valr, g.permr,
+      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp2, tb, g.keyr, g.keyr_s, g.valr, g.permr,
                                             (size_t)M, 0, bits_for((uint32_t)(2 * R)), c->stream));
     }
     {

@@ -3,6 +3,7 @@
 //   backward (tf.gradients(loss, weights), code/optimization/abstract.py:117-118; formulas SURVEY 8a a15)
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <new>
 
 #include "rgcn_internal.h"
@@ -51,13 +52,14 @@ StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), act
 StreamScope::~StreamScope() { c->stream = saved; }
 
 rgcn_status stream_join(rgcn_ctx* c, int k) {
-  if (!c->use_aux) return RGCN_OK;
+  if (!c->use_aux || c->stream != c->main_stream) return RGCN_OK;   // nothing was forked
   RGCN_HIP(c, hipEventRecord(c->ev_join[k], c->aux[k]));
   RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[k], 0));
   return RGCN_OK;
 }
 
 static rgcn_status sync_all(rgcn_ctx* c) {
+  if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
   for (int k = 0; k < 2; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipStreamSynchronize(c->main_stream));
@@ -129,6 +131,7 @@ static int auto_split_k(int M, int N, int K) {
 
 static rgcn_status check_dev_flag(rgcn_ctx* c) {
   int32_t flag = 0;
+  if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
   for (int k = 0; k < 2; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipMemcpyAsync(&flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -155,6 +158,7 @@ static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes
 static void free_all(rgcn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
+  if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
   for (int k = 0; k < 2; ++k)
     if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
   if (c->main_stream) (void)hipStreamSynchronize(c->main_stream);
@@ -178,7 +182,7 @@ static void free_all(rgcn_ctx* c) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->sort_tmp2) (void)hipFree(c->sort_tmp2);
+  if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
   if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
   delete c;
 }
@@ -310,7 +314,11 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_TRY(dmalloc(c, &c->stage, stage, false));
   RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 31) / 32) * d));
   RGCN_TRY(dmalloc(c, &c->zeros, 64));
-  RGCN_TRY(graph_alloc(c));
+  RGCN_TRY(graph_alloc(c, nullptr));
+  std::swap(c->g, c->g_alt);
+  RGCN_TRY(graph_alloc(c, &c->g_alt));
+  std::swap(c->g, c->g_alt);
+  RGCN_HIP(c, hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
   {
     std::vector<int32_t> owner(c->R);
     for (int r = 0; r < c->R; ++r) owner[r] = r % c->world;
@@ -710,9 +718,45 @@ rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int
                              uint64_t seed, const float* dcodes_dev) {
   RGCN_NEED(c);
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
-  RGCN_TRY(graph_build(c, tri_dev, E));
+  if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E) {
+    // the structures for this graph were prepared beside the previous step: swap them in
+    std::swap(c->g, c->g_alt);
+    c->g.pf_valid = false;
+    c->fwd_done = false;
+    RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
+  } else {
+    RGCN_TRY(graph_build(c, tri_dev, E));
+  }
   RGCN_TRY(forward_all(c, train, seed, nullptr));
-  return backward_all(c, dcodes_dev);
+  RGCN_TRY(backward_all(c, dcodes_dev));
+  RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (E > 0 && !tri_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
+  // build into the INACTIVE set on the prefetch stream; it only has to wait for the last step that
+  // used that set (not for the step currently queued on the main stream)
+  std::swap(c->g, c->g_alt);
+  rgcn_status s = RGCN_OK;
+  do {
+    if (hipStreamWaitEvent(c->pf_stream, c->g.ev_free, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
+    c->stream = c->pf_stream;
+    const bool was_done = c->fwd_done;
+    s = graph_build(c, tri_dev, E);
+    c->fwd_done = was_done;          // the ACTIVE set's forward state is untouched
+    c->stream = c->main_stream;
+    if (s != RGCN_OK) break;
+    if (hipEventRecord(c->g.ev_ready, c->pf_stream) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipEventRecord"; break; }
+    c->g.pf_tri = tri_dev;
+    c->g.pf_E = E;
+    c->g.pf_valid = true;
+  } while (0);
+  c->stream = c->main_stream;
+  std::swap(c->g, c->g_alt);
+  return s;
 }
 
 rgcn_status rgcn_set_relation_owner(rgcn_ctx* c, const int32_t* owner, int32_t count) {
@@ -721,7 +765,10 @@ rgcn_status rgcn_set_relation_owner(rgcn_ctx* c, const int32_t* owner, int32_t c
   for (int r = 0; r < count; ++r)
     if (owner[r] < 0 || owner[r] >= c->world) RGCN_FAIL(c, RGCN_ERR_INVALID, "owner[r] outside [0, world)");
   c->g.ready = false;
+  c->g.pf_valid = false;
+  c->g_alt.pf_valid = false;
   c->fwd_done = false;
+  RGCN_TRY(sync_all(c));
   return to_dev(c, c->g.owner, owner, sizeof(int32_t) * (size_t)count);
 }
 

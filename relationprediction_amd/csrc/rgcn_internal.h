@@ -133,7 +133,14 @@ struct GraphBufs {
   int32_t *d_msg = nullptr, *s_msg = nullptr;   // inverse maps: destination- / source-order slot -> message
   float* m_norm = nullptr;
   void* sort_tmp = nullptr;
+  void* sort_tmp2 = nullptr;    // second radix-sort workspace (relation sort on a side stream)
   size_t sort_tmp_bytes = 0;
+  // prefetch bookkeeping (rgcn_prefetch_graph_device): which graph this set was prepared for
+  const int32_t* pf_tri = nullptr;
+  int64_t pf_E = -1;
+  bool pf_valid = false;
+  hipEvent_t ev_ready = nullptr;   // recorded on the prefetch stream when the set is complete
+  hipEvent_t ev_free = nullptr;    // recorded on the main stream when the last step using the set ended
   int32_t* owner = nullptr;     // [R]
   int32_t* errflag = nullptr;   // device int: nonzero = bad id seen
   bool ready = false;
@@ -170,14 +177,15 @@ struct rgcn_ctx {
   size_t slab_floats = 0;
   float* slab_dw = nullptr;              // per-chunk dW slabs of the block-diagonal backward
   size_t slab_dw_floats = 0;
-  void* sort_tmp2 = nullptr;             // second radix-sort workspace (relation sort on a side stream)
   float* stage = nullptr;                // host<->device staging for layout conversion
   size_t stage_floats = 0;
   uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
   float* colsum_part = nullptr;
   float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
 
-  rgcn::GraphBufs g;
+  rgcn::GraphBufs g;                     // ACTIVE graph structures
+  rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
+  hipStream_t pf_stream = nullptr;       // stream of rgcn_prefetch_graph_device
   int chunk = 48;                        // messages per relation chunk
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
 
@@ -223,7 +231,7 @@ struct ProfScope {
 };
 
 // ---- graph_prep.hip
-rgcn_status graph_alloc(rgcn_ctx* c);
+rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share);
 void graph_free(rgcn_ctx* c);
 rgcn_status graph_build(rgcn_ctx* c, const int32_t* triples_dev, int64_t E);
 

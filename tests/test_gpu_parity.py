@@ -224,6 +224,47 @@ def test_bitwise_deterministic(native):
         np.testing.assert_array_equal(g1[k], g2[k])
 
 
+def test_prefetched_graph_gives_identical_step(native):
+    """rgcn_prefetch_graph_device + rgcn_step_device == rgcn_step_device alone (bitwise), alternating graphs."""
+    V, R, d, L, nb, E = 150, 9, 20, 2, 4, 800
+    params, tri_a, _, dcodes = make_case(V, R, d, L, "block", nb, E, seed=31)
+    _, tri_b, _, _ = make_case(V, R, d, L, "block", nb, E, seed=32)
+    results = []
+    for prefetch in (False, True):
+        eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+        try:
+            eng.set_params(params)
+            ga, gb, dc = eng.to_device(tri_a), eng.to_device(tri_b), eng.to_device(dcodes)
+            graphs = [ga, gb]
+            out = []
+            for i in range(5):
+                eng.step_device(graphs[i % 2], E, dc, train=True, seed=100 + i)
+                if prefetch:
+                    eng.prefetch_graph_device(graphs[(i + 1) % 2], E)
+                out.append((eng.codes(), eng.get_grad("W_f1"), eng.get_grad("W_emb")))
+            results.append(out)
+            for b in (ga, gb, dc):
+                b.free()
+        finally:
+            eng.close()
+    for (c0, w0, e0), (c1, w1, e1) in zip(*results):
+        np.testing.assert_array_equal(c0, c1)
+        np.testing.assert_array_equal(w0, w1)
+        np.testing.assert_array_equal(e0, e1)
+    # and the values are right: last step (i = 4 -> graph a, seed 104) against the oracle
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(tri_a)
+        eng.forward(train=True, seed=104)
+        masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
+    finally:
+        eng.close()
+    oacts, ograds = oracle.encoder_step(params, tri_a, V, L, "block", dcodes, dropout_masks=masks)
+    assert float(np.abs(results[1][-1][0] - oacts[-1]).max()) <= FWD_ATOL
+    assert_close(results[1][-1][1], ograds["W_f1"], name="W_f1 after prefetch")
+
+
 def test_param_round_trip_and_layout(native):
     V, R, d, L, nb = 30, 7, 20, 2, 4
     params, _, _, _ = make_case(V, R, d, L, "block", nb, 5, seed=3)
