@@ -34,6 +34,9 @@ WORKLOADS = {
     "fb237_block": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 15000),
     "fb237_block_fullgraph": ("fb237_valid_test", 14541, 237, 500, 2, "block", 100, 38001),
     "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
+    # BASELINE.json configs[2]: basis decomposition, B = 2 (and settings/gcn_basis.exp's own B = 5)
+    "fb237_basis_b2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 15000),
+    "fb237_basis_b5": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 5, 15000),
 }
 
 
@@ -186,14 +189,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "processed edges/sec (R-GCN forward+backward), FB15k-237 gcn_block",
+            "metric": "processed edges/sec (R-GCN forward+backward), FB15k-237 gcn_%s" % kind,
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "real FB15k-237 valid+test graph structure (15,000-edge minibatch per SURVEY 8d), "
                     "reference-distribution random-init weights, synthetic upstream gradient",
             "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
-                       "kind": kind, "num_blocks": nb, "graph_edges": E_g,
+                       "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
                        "step": "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
                                "two alternating minibatches, next graph's prep pipelined on a side stream"
                                if pipeline else

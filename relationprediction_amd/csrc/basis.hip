@@ -41,124 +41,250 @@ __device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
   return ds.mask[idx] ? ds.inv_keep : 0.0f;
 }
 
+constexpr int kRowThreads = 1024;
+constexpr int kLongBlocks = 64;    // leading workgroups of a row launch that walk the long-row list
+
 struct AggArgs {
   const float* Hin;          // [V,d]
   float* Z;                  // [V, 2B*d]
   const int32_t* row_ptr;    // incidence CSR (rows = destinations)
-  const int32_t* slot_msg;   // slot -> position j in the relation-sorted message list
-  const int32_t* m_src;
-  const uint32_t* m_rel;     // directed relation id of message j (sorted keys)
-  const float* m_norm;
+  const int32_t* d_src;      // per slot: source vertex, directed relation, normalisation
+  const int32_t* d_rel;
+  const float* d_norm;
   const float* coef;         // [2R][B]
+  const int32_t* long_rows;
+  const int32_t* nlong;
   int32_t V, d, B, R, b0, nbt;
 };
 
-// One group of TPR lanes per destination row; forward-direction messages (rel < R) feed the first B
-// column blocks of the row, backward-direction ones the last B (wave-uniform branch, static registers).
+// accumulate one slot into the forward- or backward-direction accumulators (wave-uniform branch)
+template <int VEC>
+__device__ __forceinline__ void agg_entry(const AggArgs& a, int rel, float nrm, const float (&x)[VEC],
+                                          float (&accf)[BT][VEC], float (&accb)[BT][VEC]) {
+  const float* cf = a.coef + (size_t)rel * a.B + a.b0;
+  if (rel < a.R) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      if (b < a.nbt) {
+        const float w = nrm * cf[b];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) accf[b][k] = fmaf(w, x[k], accf[b][k]);
+      }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      if (b < a.nbt) {
+        const float w = nrm * cf[b];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) accb[b][k] = fmaf(w, x[k], accb[b][k]);
+      }
+  }
+}
+
+// slots [s0, s1) with stride `step` of one row, for one vector column: 4 gathers in flight
+template <int VEC>
+__device__ __forceinline__ void agg_range(const AggArgs& a, int s0, int s1, int step, int cidx,
+                                          float (&accf)[BT][VEC], float (&accb)[BT][VEC]) {
+  int s = s0;
+  for (; s + 3 * step < s1; s += 4 * step) {
+    int src[4], rel[4];
+    float nrm[4], x[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      src[u] = a.d_src[s + u * step]; rel[u] = a.d_rel[s + u * step]; nrm[u] = a.d_norm[s + u * step];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vload<VEC>(a.Hin + (size_t)src[u] * a.d + (size_t)cidx * VEC, x[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) agg_entry<VEC>(a, rel[u], nrm[u], x[u], accf, accb);
+  }
+  for (; s < s1; s += step) {
+    float x[VEC];
+    vload<VEC>(a.Hin + (size_t)a.d_src[s] * a.d + (size_t)cidx * VEC, x);
+    agg_entry<VEC>(a, a.d_rel[s], a.d_norm[s], x, accf, accb);
+  }
+}
+
+// Workgroups [0, n_long_blocks): one LONG row at a time, 8 slot-lanes x 128 column lanes, partial sums
+// combined through LDS in a fixed order.  The others: TPR lanes per destination row, 1024/TPR rows per
+// workgroup.  Forward-direction messages (rel < R) feed the first B column blocks, backward the last B.
 template <int VEC, int TPR>
-__global__ void __launch_bounds__(256) k_basis_agg(AggArgs a) {
-  const int v = blockIdx.x * (256 / TPR) + threadIdx.x / TPR;
+__global__ void __launch_bounds__(kRowThreads) k_basis_agg(AggArgs a, int n_long_blocks) {
+  const int nvec = a.d / VEC;
+  const size_t zstride = (size_t)2 * a.B * a.d;
+  if ((int)blockIdx.x < n_long_blocks) {
+    __shared__ float red[8][128 * VEC];
+    const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int n = *a.nlong;
+    for (int lb = blockIdx.x; lb < n; lb += n_long_blocks) {
+      const int v = a.long_rows[lb];
+      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      for (int c0 = 0; c0 < nvec; c0 += 128) {
+        const int cidx = c0 + cl;
+        float accf[BT][VEC], accb[BT][VEC];
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) { accf[b][k] = 0.f; accb[b][k] = 0.f; }
+        if (cidx < nvec) agg_range<VEC>(a, beg + sl, end, 8, cidx, accf, accb);
+#pragma unroll
+        for (int q = 0; q < 2 * BT; ++q) {
+          const int b = q % BT;
+          if (b < a.nbt) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = q < BT ? accf[b][k] : accb[b][k];
+            __syncthreads();
+            if (sl == 0 && cidx < nvec) {
+              float t[VEC];
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) {
+                float u = red[0][cl * VEC + k];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) u += red[w][cl * VEC + k];
+                t[k] = u;
+              }
+              const int blk = (q < BT ? 0 : a.B) + a.b0 + b;
+              vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)blk * a.d + (size_t)cidx * VEC, t);
+            }
+            __syncthreads();
+          }
+        }
+      }
+    }
+    return;
+  }
+  const int v = ((int)blockIdx.x - n_long_blocks) * (kRowThreads / TPR) + threadIdx.x / TPR;
   if (v >= a.V) return;
   const int lane = threadIdx.x % TPR;
-  const int nvec = a.d / VEC;
   const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
-  const size_t zrow = (size_t)v * 2 * a.B * a.d;
+  if (end - beg > kLongRow) return;      // a long-row workgroup of this launch owns it
   for (int cidx = lane; cidx < nvec; cidx += TPR) {
     float accf[BT][VEC], accb[BT][VEC];
 #pragma unroll
     for (int b = 0; b < BT; ++b)
 #pragma unroll
       for (int k = 0; k < VEC; ++k) { accf[b][k] = 0.f; accb[b][k] = 0.f; }
-    for (int s = beg; s < end; ++s) {
-      const int j = a.slot_msg[s];
-      const int rel = (int)a.m_rel[j];
-      const float nrm = a.m_norm[j];
-      float x[VEC];
-      vload<VEC>(a.Hin + (size_t)a.m_src[j] * a.d + (size_t)cidx * VEC, x);
-      const float* cf = a.coef + (size_t)rel * a.B + a.b0;
-      if (rel < a.R) {
-#pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < a.nbt) {
-            const float w = nrm * cf[b];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) accf[b][k] = fmaf(w, x[k], accf[b][k]);
-          }
-      } else {
-#pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < a.nbt) {
-            const float w = nrm * cf[b];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) accb[b][k] = fmaf(w, x[k], accb[b][k]);
-          }
-      }
-    }
+    agg_range<VEC>(a, beg, end, 1, cidx, accf, accb);
 #pragma unroll
     for (int b = 0; b < BT; ++b)
       if (b < a.nbt) {
-        vstore<VEC>(a.Z + zrow + (size_t)(a.b0 + b) * a.d + (size_t)cidx * VEC, accf[b]);
-        vstore<VEC>(a.Z + zrow + (size_t)(a.B + a.b0 + b) * a.d + (size_t)cidx * VEC, accb[b]);
+        vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)(a.b0 + b) * a.d + (size_t)cidx * VEC, accf[b]);
+        vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)(a.B + a.b0 + b) * a.d + (size_t)cidx * VEC, accb[b]);
       }
   }
 }
 
 struct BwdGatherArgs {
   const float* dZ;           // [V, 2B*d]
-  const int32_t* row_ptr;    // incidence CSR (rows = sources)
-  const int32_t* slot_msg;   // source-order slot -> j
-  const int32_t* m_dst;
-  const uint32_t* m_rel;
-  const float* m_norm;
+  const int32_t* row_ptr;    // incidence CSR (rows = sources); nullptr: no relational part
+  const int32_t* s_dst;      // per source-order slot: destination vertex, directed relation, normalisation
+  const int32_t* s_rel;
+  const float* s_norm;
   const float* coef;         // [2R][B]
+  const int32_t* long_rows;
+  const int32_t* nlong;
   int32_t B, R;
   CombineArgs c;             // epilogue: out = (base + gathered) * gate ; out2 = out * dropout
 };
 
+// acc += sum over slots [s0, s1) step `step` of  n * sum_b C[rel,b] * dZ[dst, dir, b, :]
+template <int VEC>
+__device__ __forceinline__ void gather_range(const BwdGatherArgs& a, int s0, int s1, int step, int d,
+                                             int cidx, float (&acc)[VEC]) {
+  for (int s = s0; s < s1; s += 2 * step) {
+    const bool two = s + step < s1;
+    const int dst0 = a.s_dst[s], rel0 = a.s_rel[s];
+    const float n0 = a.s_norm[s];
+    const int dst1 = two ? a.s_dst[s + step] : dst0, rel1 = two ? a.s_rel[s + step] : rel0;
+    const float n1 = two ? a.s_norm[s + step] : 0.f;
+    const float* z0 = a.dZ + ((size_t)dst0 * 2 * a.B + (rel0 < a.R ? 0 : a.B)) * d + (size_t)cidx * VEC;
+    const float* z1 = a.dZ + ((size_t)dst1 * 2 * a.B + (rel1 < a.R ? 0 : a.B)) * d + (size_t)cidx * VEC;
+    const float* c0 = a.coef + (size_t)rel0 * a.B;
+    const float* c1 = a.coef + (size_t)rel1 * a.B;
+    for (int b = 0; b < a.B; ++b) {
+      float v0[VEC], v1[VEC];
+      vload<VEC>(z0 + (size_t)b * d, v0);
+      vload<VEC>(z1 + (size_t)b * d, v1);
+      const float w0 = n0 * c0[b], w1 = n1 * c1[b];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(w1, v1[k], fmaf(w0, v0[k], acc[k]));
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void gather_epilogue(const BwdGatherArgs& a, int v, size_t off, float (&acc)[VEC]) {
+  if (a.c.base != nullptr && v >= a.c.row_lo && v < a.c.row_hi) {
+    float bs[VEC];
+    vload<VEC>(a.c.base + off, bs);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += bs[k];
+  }
+  if (a.c.gate != nullptr) {
+    float gt[VEC];
+    vload<VEC>(a.c.gate + off, gt);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = gt[k] > 0.f ? acc[k] : 0.f;
+  }
+  vstore<VEC>(a.c.out + off, acc);
+  if (a.c.out2 != nullptr) {
+    float o2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_scale(a.c.drop2, off + k);
+    vstore<VEC>(a.c.out2 + off, o2);
+  }
+}
+
 template <int VEC, int TPR>
-__global__ void __launch_bounds__(256) k_basis_bwd_gather(BwdGatherArgs a) {
-  const int v = blockIdx.x * (256 / TPR) + threadIdx.x / TPR;
-  if (v >= a.c.V) return;
-  const int lane = threadIdx.x % TPR;
+__global__ void __launch_bounds__(kRowThreads) k_basis_bwd_gather(BwdGatherArgs a, int n_long_blocks) {
   const int d = a.c.d;
   const int nvec = d / VEC;
+  if ((int)blockIdx.x < n_long_blocks) {
+    __shared__ float red[8][128 * VEC];
+    const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int n = *a.nlong;
+    for (int lb = blockIdx.x; lb < n; lb += n_long_blocks) {
+      const int v = a.long_rows[lb];
+      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      for (int c0 = 0; c0 < nvec; c0 += 128) {
+        const int cidx = c0 + cl;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        if (cidx < nvec) gather_range<VEC>(a, beg + sl, end, 8, d, cidx, acc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+        __syncthreads();
+        if (sl == 0 && cidx < nvec) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            float u = red[0][cl * VEC + k];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) u += red[w][cl * VEC + k];
+            acc[k] = u;
+          }
+          gather_epilogue<VEC>(a, v, (size_t)v * d + (size_t)cidx * VEC, acc);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  const int v = ((int)blockIdx.x - n_long_blocks) * (kRowThreads / TPR) + threadIdx.x / TPR;
+  if (v >= a.c.V) return;
+  const int lane = threadIdx.x % TPR;
   int beg = 0, end = 0;
-  if (a.row_ptr != nullptr) { beg = a.row_ptr[v]; end = a.row_ptr[v + 1]; }
-  const bool base_valid = a.c.base != nullptr && v >= a.c.row_lo && v < a.c.row_hi;
+  if (a.row_ptr != nullptr) {
+    beg = a.row_ptr[v];
+    end = a.row_ptr[v + 1];
+    if (end - beg > kLongRow) return;
+  }
   for (int cidx = lane; cidx < nvec; cidx += TPR) {
-    const size_t off = (size_t)v * d + (size_t)cidx * VEC;
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    if (base_valid) vload<VEC>(a.c.base + off, acc);
-    for (int s = beg; s < end; ++s) {
-      const int j = a.slot_msg[s];
-      const int rel = (int)a.m_rel[j];
-      const float nrm = a.m_norm[j];
-      const int dirb = rel < a.R ? 0 : a.B;
-      const float* zp = a.dZ + ((size_t)a.m_dst[j] * 2 * a.B + dirb) * d + (size_t)cidx * VEC;
-      const float* cf = a.coef + (size_t)rel * a.B;
-      for (int b = 0; b < a.B; ++b) {
-        float z[VEC];
-        vload<VEC>(zp + (size_t)b * d, z);
-        const float w = nrm * cf[b];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(w, z[k], acc[k]);
-      }
-    }
-    if (a.c.gate != nullptr) {
-      float gt[VEC];
-      vload<VEC>(a.c.gate + off, gt);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = gt[k] > 0.f ? acc[k] : 0.f;
-    }
-    vstore<VEC>(a.c.out + off, acc);
-    if (a.c.out2 != nullptr) {
-      float o2[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_scale(a.c.drop2, off + k);
-      vstore<VEC>(a.c.out2 + off, o2);
-    }
+    gather_range<VEC>(a, beg, end, 1, d, cidx, acc);
+    gather_epilogue<VEC>(a, v, (size_t)v * d + (size_t)cidx * VEC, acc);
   }
 }
 
@@ -264,19 +390,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z) {
   AggArgs a;
-  a.Hin = Hin; a.Z = Z; a.row_ptr = c->g.row_ptr; a.slot_msg = c->g.d_msg; a.m_src = c->g.m_src;
-  a.m_rel = c->g.keyr_s; a.m_norm = c->g.m_norm; a.coef = c->layers[layer].coef;
+  a.Hin = Hin; a.Z = Z; a.row_ptr = c->g.row_ptr; a.d_src = c->g.d_src; a.d_rel = c->g.d_rel;
+  a.d_norm = c->g.d_norm; a.coef = c->layers[layer].coef; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong;
   a.V = c->V; a.d = c->d; a.B = c->B; a.R = c->R;
   const bool vec4 = (c->d % 4 == 0) && aligned16(Hin) && aligned16(Z);
   const int nvec = vec4 ? c->d / 4 : c->d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-  dim3 grid((c->V + 256 / tpr - 1) / (256 / tpr)), block(256);
+  const int rpb = kRowThreads / tpr;
+  dim3 grid(kLongBlocks + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
   for (int b0 = 0; b0 < c->B; b0 += BT) {
     a.b0 = b0;
     a.nbt = c->B - b0 < BT ? c->B - b0 : BT;
     ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + 2.0 * a.nbt * c->V) + 20.0 * M, 4.0 * M * a.nbt * c->d);
-#define RGCN_LAUNCH_AGG(VEC, TPR) hipLaunchKernelGGL((k_basis_agg<VEC, TPR>), grid, block, 0, c->stream, a)
+#define RGCN_LAUNCH_AGG(VEC, TPR) \
+  hipLaunchKernelGGL((k_basis_agg<VEC, TPR>), grid, block, 0, c->stream, a, kLongBlocks)
     if (vec4) {
       if (tpr == 64) RGCN_LAUNCH_AGG(4, 64); else if (tpr == 128) RGCN_LAUNCH_AGG(4, 128); else RGCN_LAUNCH_AGG(4, 256);
     } else {
@@ -293,16 +421,20 @@ rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const
   BwdGatherArgs a;
   a.dZ = dZ;
   a.row_ptr = with_messages ? c->g.row_ptr : nullptr;
-  a.slot_msg = c->g.s_msg; a.m_dst = c->g.m_dst; a.m_rel = c->g.keyr_s; a.m_norm = c->g.m_norm;
-  a.coef = c->layers[layer].coef; a.B = c->B; a.R = c->R; a.c = ca;
+  a.s_dst = c->g.s_dst; a.s_rel = c->g.s_rel; a.s_norm = c->g.s_norm;
+  a.coef = c->layers[layer].coef; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong;
+  a.B = c->B; a.R = c->R; a.c = ca;
   const bool vec4 = (c->d % 4 == 0) && aligned16(dZ) && aligned16(ca.out) && aligned16(ca.base) &&
                     aligned16(ca.gate) && aligned16(ca.out2);
   const int nvec = vec4 ? c->d / 4 : c->d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-  dim3 grid((c->V + 256 / tpr - 1) / (256 / tpr)), block(256);
+  const int rpb = kRowThreads / tpr;
+  const int nlb = with_messages ? kLongBlocks : 0;
+  dim3 grid(nlb + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
   ProfScope ps(c, "basis_bwd_gather", 4.0 * c->d * (M * c->B + 4.0 * c->V) + 20.0 * M, 2.0 * M * c->B * c->d);
-#define RGCN_LAUNCH_BG(VEC, TPR) hipLaunchKernelGGL((k_basis_bwd_gather<VEC, TPR>), grid, block, 0, c->stream, a)
+#define RGCN_LAUNCH_BG(VEC, TPR) \
+  hipLaunchKernelGGL((k_basis_bwd_gather<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
   if (vec4) {
     if (tpr == 64) RGCN_LAUNCH_BG(4, 64); else if (tpr == 128) RGCN_LAUNCH_BG(4, 128); else RGCN_LAUNCH_BG(4, 256);
   } else {

@@ -199,8 +199,9 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
                              const int32_t* __restrict__ pos, const int32_t* __restrict__ indeg,
                              const int32_t* __restrict__ outdeg, const int32_t* __restrict__ cum_in,
                              const int32_t* __restrict__ cum_out, int32_t* m_src, int32_t* m_dst,
-                             int32_t* m_dslot, int32_t* m_sslot, float* m_norm, int32_t* d_msg,
-                             int32_t* s_msg) {
+                             int32_t* m_dslot, int32_t* m_sslot, float* m_norm,
+                             const uint32_t* __restrict__ keyr_s, int slot_arrays, int32_t* d_src,
+                             int32_t* d_rel, float* d_norm, int32_t* s_dst, int32_t* s_rel, float* s_norm) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 2 * E) return;
   if (j >= rel_ptr[2 * R]) return;    // beyond the owned messages
@@ -227,8 +228,11 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
   const int ds = pos[m], ss = pos[fwd ? m + E : m - E];
   m_dslot[j] = ds;
   m_sslot[j] = ss;
-  d_msg[ds] = j;
-  s_msg[ss] = j;
+  if (slot_arrays) {
+    const int rel2 = (int)keyr_s[j];
+    d_src[ds] = src; d_rel[ds] = rel2; d_norm[ds] = norm;
+    s_dst[ss] = dst; s_rel[ss] = rel2; s_norm[ss] = norm;
+  }
 }
 
 int bits_for(uint32_t max_value) {
@@ -277,8 +281,14 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   RGCN_TRY(dalloc(c, &g.m_dslot, M));
   RGCN_TRY(dalloc(c, &g.m_sslot, M));
   RGCN_TRY(dalloc(c, &g.m_norm, M));
-  RGCN_TRY(dalloc(c, &g.d_msg, M));
-  RGCN_TRY(dalloc(c, &g.s_msg, M));
+  if (c->kind == RGCN_KIND_BASIS) {
+    RGCN_TRY(dalloc(c, &g.d_src, M));
+    RGCN_TRY(dalloc(c, &g.d_rel, M));
+    RGCN_TRY(dalloc(c, &g.d_norm, M));
+    RGCN_TRY(dalloc(c, &g.s_dst, M));
+    RGCN_TRY(dalloc(c, &g.s_rel, M));
+    RGCN_TRY(dalloc(c, &g.s_norm, M));
+  }
   if (share) {
     g.owner = share->owner;
     g.errflag = share->errflag;
@@ -313,7 +323,8 @@ static void graph_free_one(GraphBufs& g, bool owns_shared) {
   if (g.ev_free) (void)hipEventDestroy(g.ev_free);
   void* ptrs[] = {g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
-                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg, g.owner, g.errflag, g.sort_tmp,
+                  g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel,
+                  g.s_norm, g.owner, g.errflag, g.sort_tmp,
                   g.sort_tmp2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -379,7 +390,8 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     ProfScope ps(c, "prep_build_msgs", 12.0 * E + 36.0 * M, 0);
     hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
                        c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
-                       g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_msg, g.s_msg);
+                       g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.keyr_s,
+                       c->kind == RGCN_KIND_BASIS ? 1 : 0, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel, g.s_norm);
   }
   RGCN_HIP(c, hipGetLastError());
   g.ready = true;

@@ -130,7 +130,10 @@ struct GraphBufs {
   int32_t* pos = nullptr;       // [2maxE] incidence -> CSR slot
   // relation-sorted message list (SoA, [2maxE] each)
   int32_t *m_src = nullptr, *m_dst = nullptr, *m_dslot = nullptr, *m_sslot = nullptr;
-  int32_t *d_msg = nullptr, *s_msg = nullptr;   // inverse maps: destination- / source-order slot -> message
+  // slot-ordered copies for the row-major gathers of the basis path (destination order: d_*, source
+  // order: s_*): partner vertex, directed relation, normalisation of the message in that slot
+  int32_t *d_src = nullptr, *d_rel = nullptr, *s_dst = nullptr, *s_rel = nullptr;
+  float *d_norm = nullptr, *s_norm = nullptr;
   float* m_norm = nullptr;
   void* sort_tmp = nullptr;
   void* sort_tmp2 = nullptr;    // second radix-sort workspace (relation sort on a side stream)
