@@ -163,11 +163,27 @@ def main():
                             "avg_us": round(avg_ms * 1e3, 2), "ms_per_step": round(p["total_ms"] / args.steps, 4),
                             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                             "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/*_traffic.json, FETCH_SIZE doubled per MI355X_MICROARCH.md): not collectable live
+        traffic = {}
+        try:
+            import glob
+            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+            if tj and args.workload == "fb237_block":
+                traffic = json.load(open(tj[-1]))["kernels"]
+        except Exception:  # noqa: BLE001
+            traffic = {}
+        alias = {"gemm_self_fwd": "k_gemm_f32<true, false", "gemm_self_dh": "k_gemm_f32<true, true",
+                 "gemm_self_dw": "k_gemm_f32<false, false", "block_msg_fwd": "k_block_msg_fwd",
+                 "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine"}
+        for k in kernels:
+            pref = alias.get(k["kernel"])
+            k["traffic"] = next((round(v) for n, v in traffic.items() if pref and n.startswith(pref)), None)
         kernels.sort(key=lambda k: -k["ms_per_step"])
         if kernels:
             k = kernels[0]
             roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                        "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_us": k["avg_us"],
+                        "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_us": k["avg_us"],
                         "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
 
     # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1

@@ -72,6 +72,11 @@ def main():
     lines.append("")
     lines.append("total GPU kernel time: %.3f ms over the run" % (total / 1e6))
     open(outp, "w").write("\n".join(lines) + "\n")
+    # machine-readable HBM traffic per launch (bytes) for bench.py's roofline.traffic
+    import json
+    traffic = {k: (2 * fetch[k] + write[k]) * 1024 for k in ks if k in fetch and k in write}
+    json.dump({"source": d, "unit": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024",
+               "kernels": traffic}, open(outp.replace(".md", "_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
