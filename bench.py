@@ -63,16 +63,8 @@ def main():
 
     import numpy as np
 
-    dist = None
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
-        import torch  # noqa: F401  (test knob: exercise the torch-first load order on one GPU)
-    if world > 1:
-        # control plane only (rendezvous of the RCCL id, barriers); the data path is our own RCCL
-        # communicator on the engine's stream.  torch is imported BEFORE librgcn.so so that one HIP
-        # runtime image serves the whole process.
-        import torch  # noqa: F401
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
 
     from relationprediction_amd import _native
     from relationprediction_amd.sharding import lpt_partition
@@ -96,12 +88,38 @@ def main():
     eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
                          device=local_rank, rank=rank, world=world)
     eng.set_params(params)
+    rdv_path = None
     if world > 1:
+        # One rank per GPU (launched by torch.distributed.run, which only provides the environment).
+        # The process keeps ONE ROCm stack: no torch import here; the 128-byte RCCL id travels through a
+        # file on this node (single-node contract), everything else (barriers, max over ranks) rides on
+        # the library's own RCCL communicator.
         owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
         eng.set_relation_owner(owner)
-        ids = [_native.Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0])
+        rdv_path = "/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        if rank == 0:
+            uid = _native.Engine.comm_unique_id()
+            with open(rdv_path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(rdv_path + ".tmp", rdv_path)
+        else:
+            deadline = time.time() + 300
+            while not os.path.exists(rdv_path):
+                if time.time() > deadline:
+                    sys.exit("rank %d: timed out waiting for the RCCL id file %s" % (rank, rdv_path))
+                time.sleep(0.05)
+            with open(rdv_path, "rb") as f:
+                uid = f.read()
+        eng.comm_init(uid)
+    comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
+
+    def allgather_scalar(x):
+        """every rank's value, through a sum-all-reduce of a one-hot vector"""
+        v = np.zeros(world, dtype=np.float32)
+        v[rank] = x
+        comm_buf.upload(v)
+        eng.comm_allreduce_sum(comm_buf, world)
+        return comm_buf.download(np.float32, (world,))
     tri_dev = eng.to_device(triples)
     tri_dev_b = eng.to_device(triples_b)
     dc_dev = eng.to_device(dcodes)
@@ -110,10 +128,11 @@ def main():
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            dist.barrier()
+        if world > 1:
+            allgather_scalar(1.0)      # returns only after every rank has joined the collective
+            eng.sync()
 
-    def run(n, seed0):
+    def run(n, seed0, pipeline=pipeline):
         # step i works on graph i % 2; while it runs, the next graph's CSR / message list is prepared
         # on a side stream (what a training loop does with the next sampled minibatch)
         for i in range(n):
@@ -130,22 +149,31 @@ def main():
     eng.sync()
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    if world > 1:
+        wall = float(allgather_scalar(wall).max())     # max over ranks
+        if rank == 0 and rdv_path and os.path.exists(rdv_path):
+            os.remove(rdv_path)
     ms_per_step = wall * 1e3 / args.steps
     value = E_g * args.steps / wall
 
-    # ---- per-kernel accounting: same steps again with HIP events around every launch
+    # ---- per-kernel accounting: the same steps again with HIP events around every launch.
+    # Pass 1 as timed above (side streams + pipelined prep: durations of co-running kernels overlap and
+    # stretch); pass 2 with overlap off, every kernel alone on the main stream: EXCLUSIVE durations,
+    # which the per-kernel roofline numbers use.
     kernels, roofline = [], None
     if not args.no_kernel_profile:
         eng.profile_reset()
         eng.profile_enable(True)
         run(args.steps, 2000)
+        in_pipeline = {p["name"]: p["total_ms"] / max(p["calls"], 1) for p in eng.profile()}
+        eng.profile_enable(False)
+        eng.set_overlap(False)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        run(args.steps, 2000, pipeline=False)
         prof = eng.profile()
         eng.profile_enable(False)
+        eng.set_overlap(os.environ.get("RGCN_STREAMS", "1") != "0")
         for p in prof:
             if p["calls"] == 0:
                 continue
@@ -160,7 +188,9 @@ def main():
             else:
                 ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
             kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / args.steps,
-                            "avg_us": round(avg_ms * 1e3, 2), "ms_per_step": round(p["total_ms"] / args.steps, 4),
+                            "avg_us": round(avg_ms * 1e3, 2),
+                            "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
+                            "ms_per_step": round(p["total_ms"] / args.steps, 4),
                             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                             "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
@@ -184,6 +214,8 @@ def main():
             k = kernels[0]
             roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                         "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_us": k["avg_us"],
+                        "avg_us_in_pipeline": k["avg_us_in_pipeline"],
+                        "note": "exclusive duration (overlap off); in the pipelined step it co-runs with HBM-bound kernels",
                         "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
 
     # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
@@ -228,9 +260,9 @@ def main():
     tri_dev.free()
     tri_dev_b.free()
     dc_dev.free()
+    if comm_buf is not None:
+        comm_buf.free()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -208,6 +208,10 @@ rgcn_status rgcn_copy_to_host(rgcn_ctx* ctx, void* host, const void* dev, int64_
 rgcn_status rgcn_timer_start(rgcn_ctx* ctx);
 rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises */
 
+/* Side-stream overlap on/off (default on; RGCN_STREAMS=0 in the environment turns it off at create).
+ * With overlap off every kernel runs alone on the main stream: per-kernel durations are exclusive. */
+rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
+
 /* Per-kernel profile: when enabled every launch is bracketed by HIP events on the context's stream.
  * Records aggregate by kernel name; alg_bytes / alg_flops are the ALGORITHMIC bytes / flops of the
  * launches ("roofline accounting"), summed over calls. */

@@ -84,6 +84,7 @@ _SIGS = {
     "rgcn_copy_to_host": (C.c_int32, [_P, _P, _P, C.c_int64]),
     "rgcn_timer_start": (C.c_int32, [_P]),
     "rgcn_timer_stop": (C.c_int32, [_P, C.POINTER(C.c_float)]),
+    "rgcn_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_reset": (C.c_int32, [_P]),
     "rgcn_profile_count": (C.c_int32, [_P]),
@@ -382,6 +383,9 @@ class Engine:
         ms = C.c_float()
         self._check(self.lib.rgcn_timer_stop(self.ctx, C.byref(ms)))
         return float(ms.value)
+
+    def set_overlap(self, on=True):
+        self._check(self.lib.rgcn_set_overlap(self.ctx, 1 if on else 0))
 
     def profile_enable(self, on=True):
         self._check(self.lib.rgcn_profile_enable(self.ctx, 1 if on else 0))

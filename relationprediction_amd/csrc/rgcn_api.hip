@@ -869,6 +869,13 @@ rgcn_status rgcn_timer_stop(rgcn_ctx* c, float* ms) {
   return RGCN_OK;
 }
 
+rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
+  RGCN_NEED(c);
+  RGCN_TRY(sync_all(c));
+  c->use_aux = on != 0;
+  return RGCN_OK;
+}
+
 rgcn_status rgcn_profile_enable(rgcn_ctx* c, int32_t on) {
   RGCN_NEED(c);
   if (!on && c->prof_on) RGCN_TRY(profile_collect(c));

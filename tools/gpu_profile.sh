@@ -5,6 +5,8 @@ TAG=${1:-r01}
 mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 CMD="python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-kernel-profile"
+# second argument "serial": exclusive kernel durations (no side streams, no pipelined prep)
+if [ "$2" = "serial" ]; then export RGCN_STREAMS=0 RGCN_BENCH_PREFETCH=0; fi
 cd /tmp
 ROOTDIR=$GRAFT_REPO_ROOT
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
