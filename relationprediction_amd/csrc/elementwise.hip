@@ -90,7 +90,7 @@ __device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, si
 }
 
 constexpr int kCombineThreads = 1024;
-constexpr int kLongBlocks = 64;     // extra workgroups of the combine grid that walk the long-row list
+constexpr int kLongBlocksMin = 64;  // extra workgroups of the combine grid that walk the long-row list
 
 // Workgroups [0, nb_rows): TPR lanes per row, 1024 / TPR rows per workgroup, rows with more than
 // kLongRow slots are skipped.  Workgroups [nb_rows, nb_rows + kLongBlocks): one LONG row at a time
@@ -323,7 +323,12 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double a
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
   const int rows_per_block = kCombineThreads / tpr;
   const int nb_rows = (a.V + rows_per_block - 1) / rows_per_block;
-  const int n_long_blocks = a.msg != nullptr ? kLongBlocks : 0;
+  // enough long-row workgroups for the graph at hand: one per ~1024 slots, at least 64, at most 1024
+  int n_long_blocks = 0;
+  if (a.msg != nullptr) {
+    int64_t want = 2 * c->g.E / 1024;
+    n_long_blocks = (int)(want < kLongBlocksMin ? kLongBlocksMin : (want > 1024 ? 1024 : want));
+  }
   dim3 grid(nb_rows + n_long_blocks), block(kCombineThreads);
   ProfScope ps(c, tag, alg_bytes, 0);
 #define RGCN_LAUNCH_COMBINE(VEC, TPR) \

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
 // degrees (all fed edges, owned or not) and validate the ids.
 __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
                        const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
-                       uint32_t* keyr, int32_t* valr, int32_t* indeg, int32_t* outdeg, int32_t* errflag) {
+                       uint32_t* keyr, int32_t* valr, int count_degrees, int32_t* indeg, int32_t* outdeg,
+                       int32_t* errflag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * E) return;
   const bool fwd = i < E;
@@ -97,11 +98,13 @@ __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
   int s = tri[3 * e], r = tri[3 * e + 1], o = tri[3 * e + 2];
   bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
   if (fwd) {
-    if (ok) {
+    if (!ok) {
+      atomicOr(errflag, 1);
+    } else if (count_degrees) {
+      // sharded run: the CSR below holds only this rank's relations, so the GLOBAL degrees are counted
+      // here (a hub serialises these atomics; the single-GPU path reads them off the sorted rows instead)
       atomicAdd(&indeg[o], 1);
       atomicAdd(&outdeg[s], 1);
-    } else {
-      atomicOr(errflag, 1);
     }
   }
   bool owned = ok && owner[r] == rank;
@@ -125,7 +128,9 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_
 //   block 0  : rel_ptr[r] = lower_bound(relation keys, r) and the exclusive scan of the per-relation
 //              chunk counts (2R <= a few thousand entries: one workgroup).
 __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv_s,
-                                               const uint32_t* __restrict__ keyr_s, int M, int V, int R2,
+                                               const uint32_t* __restrict__ keyr_s,
+                                               const int32_t* __restrict__ permv, int E, int degrees_from_rows,
+                                               int32_t* indeg, int32_t* outdeg, int M, int V, int R2,
                                                int chunk, int32_t* row_ptr,
                                                int32_t* long_rows, int32_t* nlong, int cap, int32_t* rel_ptr,
                                                int32_t* chunk_ptr) {
@@ -173,6 +178,17 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   row_ptr[v] = beg;
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1));
+  if (degrees_from_rows) {
+    // all relations are local: row v holds every incidence of v, the stable sort put the incidences
+    // with index < E (edges arriving at v) first -> in-degree = position of the first index >= E
+    int lo = beg, hi = end;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (permv[mid] < E) lo = mid + 1; else hi = mid;
+    }
+    indeg[v] = lo - beg;
+    outdeg[v] = end - lo;
+  }
   if (end - beg > kLongRow) {
     const int i = atomicAdd(nlong, 1);
     if (i < cap) long_rows[i] = v;
@@ -351,7 +367,8 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
-                         c->rank, g.keyv, g.valv, g.keyr, g.valr, g.indeg, g.outdeg, g.errflag);
+                         c->rank, g.keyv, g.valv, g.keyr, g.valr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg,
+                         g.errflag);
     }
     {   // the two sorts are independent: relation sort on a side stream
       StreamScope side(c, 0);
@@ -375,7 +392,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
     hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
-                       M, V, 2 * R, c->chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
+                       g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, c->chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
                        g.rel_ptr, g.chunk_ptr);
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {

@@ -203,6 +203,9 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   c->rank = f.rank; c->world = f.world;
   if ((int64_t)c->V * c->d > (int64_t)1 << 31 || 2 * f.max_edges * (int64_t)c->d > ((int64_t)1 << 40))
     RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "problem too large for this build");
+  // messages per relation chunk: 48 at minibatch scale; grows with the capacity so that a full-graph
+  // context does not cut a popular relation into thousands of chunks
+  if (2 * f.max_edges > 65536) c->chunk = 48 * (int)((2 * f.max_edges + 65535) / 65536);
   if (const char* e = getenv("RGCN_CHUNK")) {
     const int v = atoi(e);
     if (v >= 8 && v <= 4096) c->chunk = v;
