@@ -118,7 +118,9 @@ rgcn_status rgcn_sync(rgcn_ctx* ctx);
  *                                                           (gcn_basis.py:33-37)
  * Host layouts are the reference's (row-major, shapes above); the device layout is private.
  * `b` is created but never used by the reference layers: it is stored, never read,
- * and its gradient is all zeros.  W_relation is not an encoder-path weight and stays on the host. */
+ * and its gradient is all zeros.  The LAST parameter is the decoder's W_relation [EntityCount, d]
+ * (relation_embedding.py:15-18; only rows < RelationCount are ever used): the encoder path
+ * does not touch it, the device decoder below does. */
 int32_t     rgcn_param_count(const rgcn_ctx* ctx);
 rgcn_status rgcn_param_info(const rgcn_ctx* ctx, int32_t index, char* name, int32_t name_cap,
                             int64_t shape[4], int32_t* ndim);
@@ -163,6 +165,30 @@ rgcn_status rgcn_backward_device(rgcn_ctx* ctx, const float* dcodes_dev);
  * TensorflowOptimizer.update_from_batch (optimize.py:81-88). */
 rgcn_status rgcn_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges,
                              int32_t train, uint64_t dropout_seed, const float* dcodes_dev);
+
+/* ---- "next" rows: DistMult decoder, clip + Adam, whole train step on the device ----
+ * X = int32 [N,3] (subject, relation, object) positives + sampled negatives, Y = float32 [N] labels, as
+ * NegativeSampler.transform emits them (code/common/auxilliaries.py:13-33).  Replaces the decoder part of
+ * the train graph: BilinearDiag.get_loss + local_get_regularization (code/decoders/bilinear_diag.py:27-34,
+ * 63-69) and their tf.gradients.  Needs rgcn_decoder_reserve(max N) once and a completed rgcn_forward.
+ * Leaves dL/dcodes in rgcn_dcodes_device() (feed it to rgcn_backward_device) and dL/dW_relation in the
+ * gradient of the last parameter; rgcn_get_loss returns loss + regulariser (synchronises). */
+rgcn_status rgcn_decoder_reserve(rgcn_ctx* ctx, int64_t max_triples);
+rgcn_status rgcn_decoder_loss_backward_device(rgcn_ctx* ctx, const int32_t* x_dev, const float* y_dev,
+                                              int64_t num_triples, float regularization_parameter);
+const float* rgcn_dcodes_device(rgcn_ctx* ctx);
+rgcn_status rgcn_get_loss(rgcn_ctx* ctx, double* loss);
+/* GradientClipping(max_norm) + Adam(lr) of the Converge chain (optimization/tensorflow_backend/
+ * algorithms.py:27-42,58-68).  max_grad_norm = 0 disables clipping. */
+rgcn_status rgcn_optimizer_config(rgcn_ctx* ctx, float learning_rate, float beta1, float beta2, float epsilon,
+                                  float max_grad_norm);
+rgcn_status rgcn_optimizer_step(rgcn_ctx* ctx);
+/* One TensorflowOptimizer.update_from_batch (optimize.py:81-88) entirely on the device, asynchronous:
+ * graph prep (or adoption of a prefetched one), encoder forward (train), decoder loss + gradients,
+ * encoder backward, and -- if rgcn_optimizer_config was called -- clip + Adam. */
+rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges,
+                                   const int32_t* x_dev, const float* y_dev, int64_t num_triples,
+                                   uint64_t dropout_seed, float regularization_parameter);
 
 /* Software pipelining across steps: prepare the graph structures of the NEXT minibatch (same work as
  * rgcn_set_graph_device) on a side stream into a second buffer set while the step already queued

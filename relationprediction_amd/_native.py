@@ -64,6 +64,13 @@ _SIGS = {
     "rgcn_backward": (C.c_int32, [_P, _P, C.c_int64]),
     "rgcn_backward_device": (C.c_int32, [_P, _P]),
     "rgcn_step_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_uint64, _P]),
+    "rgcn_decoder_reserve": (C.c_int32, [_P, C.c_int64]),
+    "rgcn_decoder_loss_backward_device": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_float]),
+    "rgcn_dcodes_device": (_P, [_P]),
+    "rgcn_get_loss": (C.c_int32, [_P, C.POINTER(C.c_double)]),
+    "rgcn_optimizer_config": (C.c_int32, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rgcn_optimizer_step": (C.c_int32, [_P]),
+    "rgcn_train_step_device": (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint64, C.c_float]),
     "rgcn_prefetch_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
     "rgcn_set_relation_owner": (C.c_int32, [_P, _P, C.c_int32]),
     "rgcn_comm_unique_id": (C.c_int32, [_P]),
@@ -308,6 +315,38 @@ class Engine:
     def step_device(self, triples_dev, num_edges, dcodes_dev, train=True, seed=0):
         self._check(self.lib.rgcn_step_device(self.ctx, triples_dev.ptr, int(num_edges), 1 if train else 0,
                                               C.c_uint64(seed), dcodes_dev.ptr))
+
+    # -- decoder / optimizer / whole train step on the device
+    def decoder_reserve(self, max_triples):
+        self._check(self.lib.rgcn_decoder_reserve(self.ctx, int(max_triples)))
+
+    def decoder_loss_backward_device(self, x_dev, y_dev, num_triples, reg_param):
+        self._check(self.lib.rgcn_decoder_loss_backward_device(self.ctx, x_dev.ptr, y_dev.ptr, int(num_triples),
+                                                               C.c_float(reg_param)))
+
+    def backward_from_decoder(self):
+        """encoder backward fed with the decoder's dL/dcodes (stays on the device)"""
+        self._check(self.lib.rgcn_backward_device(self.ctx, self.lib.rgcn_dcodes_device(self.ctx)))
+
+    def dcodes(self):
+        out = np.empty((self.V, self.d), dtype=np.float32)
+        self._check(self.lib.rgcn_copy_to_host(self.ctx, _ptr(out), self.lib.rgcn_dcodes_device(self.ctx), out.nbytes))
+        return out
+
+    def loss(self):
+        v = C.c_double()
+        self._check(self.lib.rgcn_get_loss(self.ctx, C.byref(v)))
+        return float(v.value)
+
+    def optimizer_config(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0):
+        self._check(self.lib.rgcn_optimizer_config(self.ctx, lr, beta1, beta2, eps, max_grad_norm))
+
+    def optimizer_step(self):
+        self._check(self.lib.rgcn_optimizer_step(self.ctx))
+
+    def train_step_device(self, triples_dev, num_edges, x_dev, y_dev, num_triples, seed=0, reg_param=0.01):
+        self._check(self.lib.rgcn_train_step_device(self.ctx, triples_dev.ptr, int(num_edges), x_dev.ptr, y_dev.ptr,
+                                                    int(num_triples), C.c_uint64(seed), C.c_float(reg_param)))
 
     def prefetch_graph_device(self, triples_dev, num_edges):
         self._check(self.lib.rgcn_prefetch_graph_device(self.ctx, triples_dev.ptr, int(num_edges)))

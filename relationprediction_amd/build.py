@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librgcn.so")
 ARCH = "gfx950"
 SOURCES = ["rgcn_api.hip", "graph_prep.hip", "gemm_f32.hip", "block_msgs.hip", "basis.hip",
-           "elementwise.hip", "comm.hip"]
+           "elementwise.hip", "decoder.hip", "optimizer.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h")]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

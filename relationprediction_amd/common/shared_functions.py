@@ -33,12 +33,14 @@ def make_bias(shape, init=0):
 
 
 def init_encoder_params(V, R, d, num_layers, kind, num_bases, rng=None):
-    """All encoder weights with the reference's distributions, in the reference's creation order
-    (outermost component first: code/model.py:156-164): top GCN layer ... bottom GCN layer
+    """All weights of the encoder/decoder pair with the reference's distributions, in the reference's
+    creation order (outermost component first: code/model.py:156-164): RelationEmbedding
+    (relation_embedding.py:15-18, randn [EntityCount, d]), top GCN layer ... bottom GCN layer
     (gcn_basis_concat.py:17-27 | gcn_basis.py:15-30), then AffineTransform (affine_transform.py:24-28).
     Returns {name: array} keyed like rgcn_param_info names."""
     rng = np.random if rng is None else rng
     p = {}
+    p["W_relation"] = rng.randn(V, d).astype(np.float32)
     for l in range(num_layers, 0, -1):
         if kind == "block":
             sd = int(d / num_bases)

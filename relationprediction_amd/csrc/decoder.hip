@@ -1,0 +1,562 @@
+// DistMult decoder on the device: energies, loss, regulariser and their gradients
+// (reference: code/decoders/bilinear_diag.py; "next" row f1 of SURVEY.md section 8f).
+//
+//   x_n   = sum_k e1_k r_k e2_k            e1 = codes[X_n0], r = W_relation[X_n1], e2 = codes[X_n2]   (:18-21,30)
+//   loss  = mean_n[(1-y_n) x_n + log1p(exp(-|x_n|)) + max(-x_n,0)]                                     (:32-34, pos_weight = 1)
+//         + lambda (mean(e1^2) + mean(r^2) + mean(e2^2))                                               (:63-69)
+//
+// The reference materialises three [N,d] gathers (660 MB each at N = 330,000) and gets their gradients
+// back as IndexedSlices.  Here nothing [N,d] is ever written:
+//   K1  one wavefront per triple: the three rows are read once, x_n, dx_n = (sigmoid(x_n) - y_n)/N and the
+//       loss terms fall out of one shuffle reduction;
+//   K2  entity gradient = segmented reduction over a by-entity CSR of the 2N (triple, side) incidences:
+//       dcodes[v] = sum_{incidences at v} dx_n (r (.) other) + (2 lambda / (N d)) cnt_v codes[v]
+//       -- the same formula for the subject and the object side, rows are independent, no atomics;
+//   K3  relation gradient = per-relation chunks of 128 triples -> slab, ordered reduce per relation.
+// The two CSRs depend only on X, not on the encoder: they are built on a side stream while the encoder's
+// forward pass runs (rgcn_train_step_device).
+#include "rgcn_internal.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace rgcn {
+
+namespace {
+
+constexpr int kDecLongRow = 256;    // entity rows with more incidences get a whole workgroup
+constexpr int kDecChunk = 128;      // triples per relation chunk
+constexpr int kRowThreads = 1024;
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *p = v[0];
+}
+
+__device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_t x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- CSR construction -----------------------------------------------------------------------
+__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t* keyv, int32_t* valv,
+                           uint32_t* keyr, int32_t* valr, int32_t* errflag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * N) return;
+  const bool subj = i < N;
+  const int n = subj ? i : i - N;
+  const int s = X[3 * n], r = X[3 * n + 1], o = X[3 * n + 2];
+  const bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
+  if (subj && !ok) atomicOr(errflag, 2);
+  keyv[i] = ok ? (uint32_t)(subj ? s : o) : (uint32_t)V;
+  valv[i] = i;
+  if (subj) {
+    keyr[n] = ok ? (uint32_t)r : (uint32_t)R;
+    valr[n] = n;
+  }
+}
+
+// block 0: relation offsets + exclusive scan of the chunk counts; blocks 1..: entity row offsets + long rows
+__global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ keyv_s,
+                                                   const uint32_t* __restrict__ keyr_s, int N, int V, int R,
+                                                   int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
+                                                   int32_t* rel_ptr, int32_t* chunk_ptr) {
+  if (blockIdx.x == 0) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base <= R; base += 1024) {
+      const int r = base + tid;
+      int lo = 0, nchunks = 0;
+      if (r <= R) {
+        lo = lower_bound_u32(keyr_s, N, (uint32_t)r);
+        rel_ptr[r] = lo;
+        if (r < R) nchunks = (lower_bound_u32(keyr_s, N, (uint32_t)(r + 1)) - lo + kDecChunk - 1) / kDecChunk;
+      }
+      int incl = nchunks;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) wsum[wid] = incl;
+      __syncthreads();
+      int wbase = 0, total = 0;
+      for (int w = 0; w < 16; ++w) {
+        if (w < wid) wbase += wsum[w];
+        total += wsum[w];
+      }
+      const int carry = carry_s;
+      if (r <= R) chunk_ptr[r] = carry + wbase + incl - nchunks;
+      __syncthreads();
+      if (tid == 0) carry_s = carry + total;
+      __syncthreads();
+    }
+    return;
+  }
+  const int v = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (v > V) return;
+  const int beg = lower_bound_u32(keyv_s, 2 * N, (uint32_t)v);
+  row_ptr[v] = beg;
+  if (v == V) return;
+  const int end = lower_bound_u32(keyv_s, 2 * N, (uint32_t)(v + 1));
+  if (end - beg > kDecLongRow) {
+    const int i = atomicAdd(nlong, 1);
+    if (i < cap) long_rows[i] = v;
+  }
+}
+
+// slot-ordered incidence arrays: the OTHER entity of the triple, its relation, the triple id
+__global__ void k_dec_slots(const int32_t* __restrict__ X, int N, const int32_t* __restrict__ permv,
+                            const int32_t* __restrict__ row_ptr, int V, int32_t* e_other, int32_t* e_rel,
+                            int32_t* e_trip) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= row_ptr[V]) return;            // invalid triples sort behind the last row
+  const int i = permv[s];
+  const int n = i < N ? i : i - N;
+  e_other[s] = i < N ? X[3 * n + 2] : X[3 * n];
+  e_rel[s] = X[3 * n + 1];
+  e_trip[s] = n;
+}
+
+// ---- K1: energies, dx, loss terms ---------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_dec_energy(const float* __restrict__ codes, const float* __restrict__ Wr,
+                                                    const int32_t* __restrict__ X, const float* __restrict__ Y,
+                                                    int N, int V, int R, int d, float* __restrict__ dx,
+                                                    float* __restrict__ part /* [gridDim.x][2] */) {
+  __shared__ float red[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d / VEC;
+  float xent = 0.f, sq = 0.f;            // accumulated by lane 0 of each wave
+  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+    const int s = X[3 * n], r = X[3 * n + 1], o = X[3 * n + 2];
+    const bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
+    float x = 0.f, q = 0.f;
+    if (ok) {
+      const float* p1 = codes + (size_t)s * d;
+      const float* pr = Wr + (size_t)r * d;
+      const float* p2 = codes + (size_t)o * d;
+      for (int c = lane; c < nvec; c += 64) {
+        float a[VEC], b[VEC], e[VEC];
+        vload<VEC>(p1 + (size_t)c * VEC, a);
+        vload<VEC>(pr + (size_t)c * VEC, b);
+        vload<VEC>(p2 + (size_t)c * VEC, e);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          x = fmaf(a[k] * b[k], e[k], x);
+          q += a[k] * a[k] + b[k] * b[k] + e[k] * e[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      x += __shfl_down(x, off, 64);
+      q += __shfl_down(q, off, 64);
+    }
+    if (lane == 0) {
+      const float y = Y[n];
+      const float ax = fabsf(x);
+      const float ex = __expf(-ax);
+      const float sig = x >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
+      dx[n] = ok ? (sig - y) / (float)N : 0.f;
+      if (ok) {
+        xent += (1.0f - y) * x + log1pf(ex) + fmaxf(-x, 0.f);
+        sq += q;
+      }
+    }
+  }
+  if (lane == 0) { red[wave][0] = xent; red[wave][1] = sq; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[(size_t)blockIdx.x * 2 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// loss = sum(xent)/N + lambda * sum(sq)/(N d)   (double accumulation, one workgroup, fixed order)
+__global__ void __launch_bounds__(256) k_dec_loss(const float* __restrict__ part, int nparts, int N, int d,
+                                                  float lambda, double* __restrict__ loss) {
+  __shared__ double red[256][2];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+  red[threadIdx.x][0] = a; red[threadIdx.x][1] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x][0] += red[threadIdx.x + s][0];
+      red[threadIdx.x][1] += red[threadIdx.x + s][1];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0][0] / (double)N + (double)lambda * red[0][1] / ((double)N * (double)d);
+}
+
+// ---- K2: entity gradients ------------------------------------------------------------------------
+struct EntArgs {
+  const float* codes;
+  const float* Wr;
+  const float* dx;
+  const int32_t* row_ptr;
+  const int32_t* e_other;
+  const int32_t* e_rel;
+  const int32_t* e_trip;
+  const int32_t* long_rows;
+  const int32_t* nlong;
+  float* dcodes;
+  int32_t V, d;
+  float k;                  // 2 lambda / (N d)
+};
+
+template <int VEC>
+__device__ __forceinline__ void ent_range(const EntArgs& a, int s0, int s1, int step, int cidx, float (&acc)[VEC]) {
+  int s = s0;
+  for (; s + 3 * step < s1; s += 4 * step) {
+    float g[4], u[4][VEC], w[4][VEC];
+    int oth[4], rel[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      oth[t] = a.e_other[s + t * step]; rel[t] = a.e_rel[s + t * step]; g[t] = a.dx[a.e_trip[s + t * step]];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      vload<VEC>(a.codes + (size_t)oth[t] * a.d + (size_t)cidx * VEC, u[t]);
+      vload<VEC>(a.Wr + (size_t)rel[t] * a.d + (size_t)cidx * VEC, w[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(g[t] * u[t][k], w[t][k], acc[k]);
+  }
+  for (; s < s1; s += step) {
+    float u[VEC], w[VEC];
+    const float g = a.dx[a.e_trip[s]];
+    vload<VEC>(a.codes + (size_t)a.e_other[s] * a.d + (size_t)cidx * VEC, u);
+    vload<VEC>(a.Wr + (size_t)a.e_rel[s] * a.d + (size_t)cidx * VEC, w);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(g * u[k], w[k], acc[k]);
+  }
+}
+
+template <int VEC, int TPR>
+__global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int n_long_blocks) {
+  const int nvec = a.d / VEC;
+  if ((int)blockIdx.x < n_long_blocks) {
+    __shared__ float red[8][128 * VEC];
+    const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int n = *a.nlong;
+    for (int lb = blockIdx.x; lb < n; lb += n_long_blocks) {
+      const int v = a.long_rows[lb];
+      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      for (int c0 = 0; c0 < nvec; c0 += 128) {
+        const int cidx = c0 + cl;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        if (cidx < nvec) ent_range<VEC>(a, beg + sl, end, 8, cidx, acc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+        __syncthreads();
+        if (sl == 0 && cidx < nvec) {
+          const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+          float self[VEC];
+          vload<VEC>(a.codes + off, self);
+          const float kc = a.k * (float)(end - beg);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            float t = red[0][cl * VEC + k];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t += red[w][cl * VEC + k];
+            acc[k] = fmaf(kc, self[k], t);
+          }
+          vstore<VEC>(a.dcodes + off, acc);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  const int v = ((int)blockIdx.x - n_long_blocks) * (kRowThreads / TPR) + threadIdx.x / TPR;
+  if (v >= a.V) return;
+  const int lane = threadIdx.x % TPR;
+  const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+  if (end - beg > kDecLongRow) return;
+  for (int cidx = lane; cidx < nvec; cidx += TPR) {
+    const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+    float acc[VEC], self[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    ent_range<VEC>(a, beg, end, 1, cidx, acc);
+    vload<VEC>(a.codes + off, self);
+    const float kc = a.k * (float)(end - beg);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(kc, self[k], acc[k]);
+    vstore<VEC>(a.dcodes + off, acc);
+  }
+}
+
+// ---- K3: relation gradients ------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int n_seg, int x) {
+  int lo = 0, hi = n_seg;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kRowThreads) k_dec_rel_partial(const float* __restrict__ codes,
+                                                                 const float* __restrict__ dx,
+                                                                 const int32_t* __restrict__ X,
+                                                                 const int32_t* __restrict__ permr,
+                                                                 const int32_t* __restrict__ rel_ptr,
+                                                                 const int32_t* __restrict__ chunk_ptr, int R,
+                                                                 int d, float* __restrict__ slab) {
+  __shared__ float red[8][128 * VEC];
+  const int bid = blockIdx.x;
+  if (bid >= chunk_ptr[R]) return;
+  const int rel = find_segment(chunk_ptr, R, bid);
+  const int beg = rel_ptr[rel] + (bid - chunk_ptr[rel]) * kDecChunk;
+  const int end = min(beg + kDecChunk, rel_ptr[rel + 1]);
+  const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  const int nvec = d / VEC;
+  for (int c0 = 0; c0 < nvec; c0 += 128) {
+    const int cidx = c0 + cl;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    if (cidx < nvec) {
+      int j = beg + sl;
+      for (; j + 8 < end; j += 16) {
+        const int n0 = permr[j], n1 = permr[j + 8];
+        float a0[VEC], b0[VEC], a1[VEC], b1[VEC];
+        vload<VEC>(codes + (size_t)X[3 * n0] * d + (size_t)cidx * VEC, a0);
+        vload<VEC>(codes + (size_t)X[3 * n0 + 2] * d + (size_t)cidx * VEC, b0);
+        vload<VEC>(codes + (size_t)X[3 * n1] * d + (size_t)cidx * VEC, a1);
+        vload<VEC>(codes + (size_t)X[3 * n1 + 2] * d + (size_t)cidx * VEC, b1);
+        const float g0 = dx[n0], g1 = dx[n1];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(g1 * a1[k], b1[k], fmaf(g0 * a0[k], b0[k], acc[k]));
+      }
+      for (; j < end; j += 8) {
+        const int n0 = permr[j];
+        float a0[VEC], b0[VEC];
+        vload<VEC>(codes + (size_t)X[3 * n0] * d + (size_t)cidx * VEC, a0);
+        vload<VEC>(codes + (size_t)X[3 * n0 + 2] * d + (size_t)cidx * VEC, b0);
+        const float g0 = dx[n0];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(g0 * a0[k], b0[k], acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+    __syncthreads();
+    if (sl == 0 && cidx < nvec) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float t = red[0][cl * VEC + k];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += red[w][cl * VEC + k];
+        acc[k] = t;
+      }
+      vstore<VEC>(slab + (size_t)bid * d + (size_t)cidx * VEC, acc);
+    }
+    __syncthreads();
+  }
+}
+
+// gWr[r] = sum of r's chunk slabs (chunk order) + k cnt_r Wr[r];   rows >= R of W_relation are never used
+__global__ void k_dec_rel_reduce(const float* __restrict__ slab, const int32_t* __restrict__ chunk_ptr,
+                                 const int32_t* __restrict__ rel_ptr, const float* __restrict__ Wr,
+                                 float* __restrict__ gWr, int R, int d, float k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * d) return;
+  const int rel = i / d, col = i - rel * d;
+  const int c0 = chunk_ptr[rel], c1 = chunk_ptr[rel + 1];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {
+    const float* p = slab + (size_t)c * d + col;
+    a0 += p[0]; a1 += p[d]; a2 += p[2 * (size_t)d]; a3 += p[3 * (size_t)d];
+  }
+  for (; c < c1; ++c) a0 += slab[(size_t)c * d + col];
+  const float cnt = (float)(rel_ptr[rel + 1] - rel_ptr[rel]);
+  gWr[i] = fmaf(k * cnt, Wr[i], (a0 + a1) + (a2 + a3));
+}
+
+int bits_for(uint32_t max_value) {
+  int b = 1;
+  while (b < 32 && (1ull << b) <= max_value) ++b;
+  return b;
+}
+
+template <class T>
+rgcn_status dalloc(rgcn_ctx* c, T** p, size_t n) {
+  RGCN_HIP(c, hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  return RGCN_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
+  DecoderBufs& q = c->dec;
+  if (q.maxN >= maxN && q.maxN > 0) return RGCN_OK;
+  decoder_free(c);
+  const size_t N = (size_t)maxN, V = c->V, R = c->R, d = c->d;
+  RGCN_TRY(dalloc(c, &q.keyv, 2 * N)); RGCN_TRY(dalloc(c, &q.keyv_s, 2 * N));
+  RGCN_TRY(dalloc(c, &q.valv, 2 * N)); RGCN_TRY(dalloc(c, &q.permv, 2 * N));
+  RGCN_TRY(dalloc(c, &q.keyr, N)); RGCN_TRY(dalloc(c, &q.keyr_s, N));
+  RGCN_TRY(dalloc(c, &q.valr, N)); RGCN_TRY(dalloc(c, &q.permr, N));
+  RGCN_TRY(dalloc(c, &q.row_ptr, V + 1)); RGCN_TRY(dalloc(c, &q.rel_ptr, R + 1)); RGCN_TRY(dalloc(c, &q.chunk_ptr, R + 1));
+  RGCN_TRY(dalloc(c, &q.e_other, 2 * N)); RGCN_TRY(dalloc(c, &q.e_rel, 2 * N)); RGCN_TRY(dalloc(c, &q.e_trip, 2 * N));
+  q.long_cap = (int32_t)(2 * N / kDecLongRow + 1);
+  RGCN_TRY(dalloc(c, &q.long_rows, (size_t)q.long_cap));
+  RGCN_TRY(dalloc(c, &q.nlong, 1));
+  RGCN_TRY(dalloc(c, &q.dx, N));
+  q.energy_blocks = 2048;
+  RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)q.energy_blocks));
+  RGCN_TRY(dalloc(c, &q.loss, 1));
+  q.max_chunks = (int32_t)(N / kDecChunk + R + 1);
+  RGCN_TRY(dalloc(c, &q.slab, (size_t)q.max_chunks * d));
+  size_t t1 = 0, t2 = 0;
+  if (N > 0) {
+    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, q.keyv, q.keyv_s, q.valv, q.permv, 2 * N, 0,
+                                          bits_for((uint32_t)c->V), c->stream));
+    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, q.keyr, q.keyr_s, q.valr, q.permr, N, 0,
+                                          bits_for((uint32_t)c->R), c->stream));
+  }
+  q.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+  RGCN_HIP(c, hipMalloc(&q.sort_tmp, q.sort_tmp_bytes));
+  RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_ready, hipEventDisableTiming));
+  if (!c->dcodes_own) RGCN_HIP(c, hipMalloc((void**)&c->dcodes_own, sizeof(float) * V * d));
+  q.maxN = maxN;
+  return RGCN_OK;
+}
+
+void decoder_free(rgcn_ctx* c) {
+  DecoderBufs& q = c->dec;
+  void* ptrs[] = {q.keyv, q.keyv_s, q.valv, q.permv, q.keyr, q.keyr_s, q.valr, q.permr, q.row_ptr, q.rel_ptr,
+                  q.chunk_ptr, q.e_other, q.e_rel, q.e_trip, q.long_rows, q.nlong, q.dx, q.loss_part, q.loss,
+                  q.slab, q.sort_tmp};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (q.ev_ready) (void)hipEventDestroy(q.ev_ready);
+  q = DecoderBufs();
+}
+
+// CSR of the decoder batch (depends on X only).  Runs on whatever stream is current.
+rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
+  DecoderBufs& q = c->dec;
+  const int N = (int)N64, V = c->V, R = c->R;
+  if (N64 > q.maxN) RGCN_FAIL(c, RGCN_ERR_INVALID, "decoder batch larger than rgcn_decoder_reserve'd");
+  q.N = N;
+  q.X = X;
+  RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, sizeof(int32_t), c->stream));
+  const int T = 256;
+  if (N > 0) {
+    {
+      ProfScope ps(c, "dec_keys", 36.0 * N, 0);
+      hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, q.keyv,
+                         q.valv, q.keyr, q.valr, c->g.errflag);
+    }
+    {
+      ProfScope ps(c, "dec_sort_entity", 32.0 * N, 0);
+      size_t tb = q.sort_tmp_bytes;
+      RGCN_HIP(c, rocprim::radix_sort_pairs(q.sort_tmp, tb, q.keyv, q.keyv_s, q.valv, q.permv, (size_t)2 * N, 0,
+                                            bits_for((uint32_t)V), c->stream));
+    }
+    {
+      ProfScope ps(c, "dec_sort_relation", 16.0 * N, 0);
+      size_t tb = q.sort_tmp_bytes;
+      RGCN_HIP(c, rocprim::radix_sort_pairs(q.sort_tmp, tb, q.keyr, q.keyr_s, q.valr, q.permr, (size_t)N, 0,
+                                            bits_for((uint32_t)R), c->stream));
+    }
+  }
+  {
+    ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);
+    hipLaunchKernelGGL(k_dec_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, q.keyv_s, q.keyr_s, N,
+                       V, R, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.rel_ptr, q.chunk_ptr);
+  }
+  if (N > 0) {
+    ProfScope ps(c, "dec_slots", 40.0 * N, 0);
+    hipLaunchKernelGGL(k_dec_slots, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, q.permv, q.row_ptr, V,
+                       q.e_other, q.e_rel, q.e_trip);
+  }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+// loss + gradients w.r.t. the codes (-> c->dcodes_own) and W_relation (-> its grad buffer)
+rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, float reg_param) {
+  DecoderBufs& q = c->dec;
+  const int N = q.N, V = c->V, R = c->R, d = c->d;
+  const float* Wr = c->w_rel;
+  float* gWr = c->g_rel;
+  if (N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "empty decoder batch");
+  const bool vec4 = (d % 4 == 0) && aligned16(codes) && aligned16(Wr) && aligned16(c->dcodes_own) && aligned16(q.slab);
+  const double Nd = (double)N * d;
+  const float k = (float)(2.0 * reg_param / Nd);
+  {
+    ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d);
+    if (vec4)
+      hipLaunchKernelGGL((k_dec_energy<4>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
+                         R, d, q.dx, q.loss_part);
+    else
+      hipLaunchKernelGGL((k_dec_energy<1>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
+                         R, d, q.dx, q.loss_part);
+    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.energy_blocks, N, d, reg_param,
+                       q.loss);
+  }
+  {
+    EntArgs a;
+    a.codes = codes; a.Wr = Wr; a.dx = q.dx; a.row_ptr = q.row_ptr; a.e_other = q.e_other; a.e_rel = q.e_rel;
+    a.e_trip = q.e_trip; a.long_rows = q.long_rows; a.nlong = q.nlong; a.dcodes = c->dcodes_own; a.V = V; a.d = d;
+    a.k = k;
+    const int nvec = vec4 ? d / 4 : d;
+    const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
+    const int rpb = kRowThreads / tpr;
+    int64_t want = 2 * (int64_t)N / 2048;
+    const int nlb = (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
+    dim3 grid(nlb + (V + rpb - 1) / rpb), block(kRowThreads);
+    ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d);
+#define RGCN_LAUNCH_EG(VEC, TPR) hipLaunchKernelGGL((k_dec_entity_grad<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
+    if (vec4) {
+      if (tpr == 64) RGCN_LAUNCH_EG(4, 64); else if (tpr == 128) RGCN_LAUNCH_EG(4, 128); else RGCN_LAUNCH_EG(4, 256);
+    } else {
+      if (tpr == 64) RGCN_LAUNCH_EG(1, 64); else if (tpr == 128) RGCN_LAUNCH_EG(1, 128); else RGCN_LAUNCH_EG(1, 256);
+    }
+#undef RGCN_LAUNCH_EG
+  }
+  {
+    ProfScope ps(c, "dec_relation_grad", 8.0 * N * d + 8.0 * R * d, 3.0 * N * d);
+    if (vec4)
+      hipLaunchKernelGGL((k_dec_rel_partial<4>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
+                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
+    else
+      hipLaunchKernelGGL((k_dec_rel_partial<1>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
+                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
+    hipLaunchKernelGGL(k_dec_rel_reduce, dim3((R * d + 255) / 256), dim3(256), 0, c->stream, q.slab, q.chunk_ptr,
+                       q.rel_ptr, Wr, gWr, R, d, k);
+  }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+}  // namespace rgcn

@@ -1,0 +1,171 @@
+// Optimizer step on the device: global-norm gradient clipping + Adam over every trainable tensor
+// ("next" row f2 of SURVEY.md 8f).  Reference chain (Appendix B): GradientClipping(max_norm) =
+// tf.clip_by_global_norm (code/optimization/tensorflow_backend/algorithms.py:58-68) wrapped around
+// Adam(learning_rate) = tf.train.AdamOptimizer(lr, beta1=0.9, beta2=0.999), epsilon 1e-8 (:27-42).
+//
+//   scale = max_norm / max(||g||_2, max_norm)                 (clip_by_global_norm)
+//   lr_t  = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   w    -= lr_t * m / (sqrt(v) + eps)                         (TF's AdamOptimizer update)
+// One table-driven launch covers all tensors (device layouts: Adam is elementwise, so the private
+// block / basis weight layouts need no conversion); the norm is a two-stage fixed-order reduction whose
+// result stays on the device -- no host synchronisation, the whole train step is one stream of launches.
+// The unused per-layer bias `b` gets no gradient in TF (None) and is skipped; W_relation is updated on
+// its first RelationCount rows only (the other rows never receive a gradient).
+// Deviation kept on purpose: TF computes the global norm over UN-aggregated IndexedSlices for gathered
+// weights; here gradients are already aggregated (trajectory parity with TF is unpinned either way).
+#include "rgcn_internal.h"
+
+namespace rgcn {
+
+namespace {
+
+constexpr int kOptThreads = 256;
+constexpr int kOptItems = 8;          // elements per thread
+constexpr int kOptMaxTensors = 40;
+
+struct OptTensor {
+  float* w;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  int32_t block0;     // first block of this tensor
+};
+struct OptTable {
+  OptTensor t[kOptMaxTensors];
+  int32_t count;
+  int32_t nblocks;
+};
+
+__device__ __forceinline__ int find_tensor(const OptTable& tab, int b) {
+  int lo = 0, hi = tab.count;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (tab.t[mid].block0 <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(kOptThreads) k_sqnorm_part(OptTable tab, float* __restrict__ part) {
+  __shared__ float red[kOptThreads / 64];
+  const int ti = find_tensor(tab, blockIdx.x);
+  const OptTensor t = tab.t[ti];
+  const int64_t base = (int64_t)(blockIdx.x - t.block0) * kOptThreads * kOptItems;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kOptItems; ++k) {
+    const int64_t i = base + (int64_t)k * kOptThreads + threadIdx.x;
+    if (i < t.n) { const float g = t.g[i]; acc = fmaf(g, g, acc); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// state[0] = clip scale, state[1] = global norm (for inspection)
+__global__ void __launch_bounds__(256) k_clip_scale(const float* __restrict__ part, int nparts, float max_norm,
+                                                    float* __restrict__ state) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    state[1] = norm;
+    state[0] = max_norm > 0.f ? max_norm / fmaxf(norm, max_norm) : 1.0f;
+  }
+}
+
+__global__ void __launch_bounds__(kOptThreads) k_adam(OptTable tab, const float* __restrict__ state, float lr_t,
+                                                      float b1, float b2, float eps) {
+  const int ti = find_tensor(tab, blockIdx.x);
+  const OptTensor t = tab.t[ti];
+  const float scale = state[0];
+  const int64_t base = (int64_t)(blockIdx.x - t.block0) * kOptThreads * kOptItems;
+#pragma unroll
+  for (int k = 0; k < kOptItems; ++k) {
+    const int64_t i = base + (int64_t)k * kOptThreads + threadIdx.x;
+    if (i < t.n) {
+      const float g = t.g[i] * scale;
+      const float m = fmaf(b1, t.m[i], (1.0f - b1) * g);
+      const float v = fmaf(b2, t.v[i], (1.0f - b2) * g * g);
+      t.m[i] = m;
+      t.v[i] = v;
+      t.w[i] -= lr_t * m / (sqrtf(v) + eps);
+    }
+  }
+}
+
+}  // namespace
+
+rgcn_status optimizer_step(rgcn_ctx* c) {
+  OptimizerState& o = c->opt;
+  if (!o.configured) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_optimizer_config was not called");
+  OptTable tab;
+  tab.count = 0;
+  int nblocks = 0;
+  if (o.m.empty()) {
+    o.m.assign(c->params.size(), nullptr);
+    o.v.assign(c->params.size(), nullptr);
+  }
+  for (size_t i = 0; i < c->params.size(); ++i) {
+    const Param& p = c->params[i];
+    if (p.no_grad) continue;                       // the never-used layer bias: TF returns None for it
+    int64_t n = p.count;
+    if (p.name == "W_relation") n = (int64_t)c->R * c->d;     // rows >= RelationCount never get a gradient
+    if (!o.m[i]) {
+      RGCN_HIP(c, hipMalloc((void**)&o.m[i], sizeof(float) * (size_t)n));
+      RGCN_HIP(c, hipMalloc((void**)&o.v[i], sizeof(float) * (size_t)n));
+      RGCN_HIP(c, hipMemsetAsync(o.m[i], 0, sizeof(float) * (size_t)n, c->stream));
+      RGCN_HIP(c, hipMemsetAsync(o.v[i], 0, sizeof(float) * (size_t)n, c->stream));
+    }
+    if (tab.count >= kOptMaxTensors) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "too many tensors for one optimizer launch");
+    OptTensor& t = tab.t[tab.count++];
+    t.w = p.val; t.g = p.grad; t.m = o.m[i]; t.v = o.v[i]; t.n = n; t.block0 = nblocks;
+    nblocks += (int)((n + kOptThreads * kOptItems - 1) / (kOptThreads * kOptItems));
+  }
+  tab.nblocks = nblocks;
+  if ((size_t)nblocks > o.part_cap) {
+    if (o.part) (void)hipFree(o.part);
+    RGCN_HIP(c, hipMalloc((void**)&o.part, sizeof(float) * (size_t)nblocks));
+    o.part_cap = (size_t)nblocks;
+  }
+  if (!o.state) {
+    RGCN_HIP(c, hipMalloc((void**)&o.state, 2 * sizeof(float)));
+  }
+  o.t += 1;
+  const double b1t = pow((double)o.beta1, (double)o.t), b2t = pow((double)o.beta2, (double)o.t);
+  const float lr_t = (float)((double)o.lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+  double total = 0;
+  for (int i = 0; i < tab.count; ++i) total += (double)tab.t[i].n;
+  {
+    ProfScope ps(c, "opt_grad_norm", 4.0 * total, 2.0 * total);
+    hipLaunchKernelGGL(k_sqnorm_part, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.part);
+    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nblocks, o.max_norm, o.state);
+  }
+  {
+    ProfScope ps(c, "opt_adam", 28.0 * total, 10.0 * total);
+    hipLaunchKernelGGL(k_adam, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.state, lr_t, o.beta1,
+                       o.beta2, o.eps);
+  }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+void optimizer_free(rgcn_ctx* c) {
+  OptimizerState& o = c->opt;
+  for (float* p : o.m) if (p) (void)hipFree(p);
+  for (float* p : o.v) if (p) (void)hipFree(p);
+  if (o.part) (void)hipFree(o.part);
+  if (o.state) (void)hipFree(o.state);
+  o = OptimizerState();
+}
+
+}  // namespace rgcn

@@ -165,7 +165,9 @@ static void free_all(rgcn_ctx* c) {
   comm_destroy(c);
   graph_free(c);
   auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb);
+  decoder_free(c);
+  optimizer_free(c);
+  F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb); F(c->w_rel); F(c->g_rel);
   for (LayerBufs& lb : c->layers) {
     F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);
   }
@@ -281,7 +283,11 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     RGCN_TRY(dmalloc(c, &lb.gbias, d));
     add_param(c, "W_self" + sl, {(int64_t)d, (int64_t)d}, lb.wself, lb.gwself, LAYOUT_PLAIN);
     add_param(c, "b" + sl, {(int64_t)d}, lb.bias, lb.gbias, LAYOUT_PLAIN);
+    c->params.back().no_grad = true;
   }
+  RGCN_TRY(dmalloc(c, &c->w_rel, Vd));
+  RGCN_TRY(dmalloc(c, &c->g_rel, Vd));
+  add_param(c, "W_relation", {(int64_t)V, (int64_t)d}, c->w_rel, c->g_rel, LAYOUT_PLAIN);
   c->H.assign(c->L + 1, nullptr);
   for (int l = 0; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->H[l], Vd));
   RGCN_TRY(dmalloc(c, &c->self_buf, Vd));
@@ -733,6 +739,82 @@ rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int
   RGCN_TRY(forward_all(c, train, seed, nullptr));
   RGCN_TRY(backward_all(c, dcodes_dev));
   RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
+  return RGCN_OK;
+}
+
+// ---- decoder / optimizer / whole train step ("next" rows f1, f2) ---------------------------------
+rgcn_status rgcn_decoder_reserve(rgcn_ctx* c, int64_t max_triples) {
+  RGCN_NEED(c);
+  if (max_triples <= 0 || max_triples > ((int64_t)1 << 30)) RGCN_FAIL(c, RGCN_ERR_INVALID, "max_triples out of range");
+  RGCN_TRY(sync_all(c));
+  return decoder_reserve(c, max_triples);
+}
+
+rgcn_status rgcn_decoder_loss_backward_device(rgcn_ctx* c, const int32_t* X_dev, const float* Y_dev, int64_t N,
+                                              float reg_param) {
+  RGCN_NEED(c);
+  if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "the decoder needs a completed rgcn_forward");
+  if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
+  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device decoder on a sharded context (not built yet)");
+  if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
+  RGCN_TRY(decoder_prepare(c, X_dev, N));
+  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
+  c->dec.loss_valid = true;
+  return RGCN_OK;
+}
+
+const float* rgcn_dcodes_device(rgcn_ctx* c) { return c ? c->dcodes_own : nullptr; }
+
+rgcn_status rgcn_get_loss(rgcn_ctx* c, double* loss) {
+  RGCN_NEED(c);
+  if (!loss) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
+  if (!c->dec.loss_valid) RGCN_FAIL(c, RGCN_ERR_STATE, "no decoder pass has run");
+  RGCN_TRY(check_dev_flag(c));
+  return to_host(c, loss, c->dec.loss, sizeof(double));
+}
+
+rgcn_status rgcn_optimizer_config(rgcn_ctx* c, float lr, float beta1, float beta2, float eps, float max_grad_norm) {
+  RGCN_NEED(c);
+  if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f) ||
+      max_grad_norm < 0.f)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad optimizer hyper-parameters");
+  c->opt.lr = lr; c->opt.beta1 = beta1; c->opt.beta2 = beta2; c->opt.eps = eps; c->opt.max_norm = max_grad_norm;
+  c->opt.configured = true;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_optimizer_step(rgcn_ctx* c) {
+  RGCN_NEED(c);
+  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device optimizer on a sharded context (not built yet)");
+  return optimizer_step(c);
+}
+
+rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, const int32_t* X_dev,
+                                   const float* Y_dev, int64_t N, uint64_t seed, float reg_param) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
+  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device train step on a sharded context (not built yet)");
+  if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
+  {   // the decoder batch's CSRs depend on X only: build them beside the encoder's forward pass
+    StreamScope side(c, 1);
+    RGCN_TRY(decoder_prepare(c, X_dev, N));
+  }
+  if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E) {
+    std::swap(c->g, c->g_alt);
+    c->g.pf_valid = false;
+    c->fwd_done = false;
+    RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
+  } else {
+    RGCN_TRY(graph_build(c, tri_dev, E));
+  }
+  RGCN_TRY(forward_all(c, 1, seed, nullptr));
+  RGCN_TRY(stream_join(c, 1));
+  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
+  c->dec.loss_valid = true;
+  RGCN_TRY(backward_all(c, c->dcodes_own));
+  RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
+  if (c->opt.configured) RGCN_TRY(optimizer_step(c));
   return RGCN_OK;
 }
 

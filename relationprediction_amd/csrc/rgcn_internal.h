@@ -94,6 +94,7 @@ struct Param {
   float* val;    // device (view into a layer allocation for W_f/W_b)
   float* grad;   // device
   int32_t layout;
+  bool no_grad = false;   // created but never used by the forward pass (the per-layer bias)
 };
 
 struct LayerBufs {
@@ -149,6 +150,35 @@ struct GraphBufs {
   bool ready = false;
 };
 
+// decoder batch structures (csrc/decoder.hip)
+struct DecoderBufs {
+  int64_t maxN = 0;
+  int32_t N = 0;
+  const int32_t* X = nullptr;
+  uint32_t *keyv = nullptr, *keyv_s = nullptr, *keyr = nullptr, *keyr_s = nullptr;
+  int32_t *valv = nullptr, *permv = nullptr, *valr = nullptr, *permr = nullptr;
+  int32_t *row_ptr = nullptr, *rel_ptr = nullptr, *chunk_ptr = nullptr;
+  int32_t *e_other = nullptr, *e_rel = nullptr, *e_trip = nullptr;
+  int32_t *long_rows = nullptr, *nlong = nullptr;
+  int32_t long_cap = 0, max_chunks = 0, energy_blocks = 0;
+  float *dx = nullptr, *loss_part = nullptr, *slab = nullptr;
+  double* loss = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  hipEvent_t ev_ready = nullptr;
+  bool loss_valid = false;
+};
+
+struct OptimizerState {
+  bool configured = false;
+  float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, max_norm = 0.f;
+  int64_t t = 0;
+  std::vector<float*> m, v;
+  float* part = nullptr;
+  size_t part_cap = 0;
+  float* state = nullptr;    // [clip scale, global norm]
+};
+
 }  // namespace rgcn
 
 struct rgcn_ctx {
@@ -166,6 +196,9 @@ struct rgcn_ctx {
   std::vector<rgcn::Param> params;
   std::vector<rgcn::LayerBufs> layers;   // index 1..L (0 unused)
   float *w_emb = nullptr, *g_emb = nullptr, *b_emb = nullptr, *gb_emb = nullptr;
+  float *w_rel = nullptr, *g_rel = nullptr;   // W_relation [EntityCount, d] (decoder weight)
+  rgcn::DecoderBufs dec;
+  rgcn::OptimizerState opt;
 
   std::vector<float*> H;                 // H[0..L], [V,d] each
   float* self_buf = nullptr;             // S / G : [V,d]
@@ -288,6 +321,14 @@ rgcn_status relu_copy(rgcn_ctx* c, const float* in, float* out, int64_t n, int r
 rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, int64_t n);
 
 DropSpec make_drop(const rgcn_ctx* c, int layer, bool active);
+
+// ---- decoder.hip / optimizer.hip
+rgcn_status decoder_reserve(rgcn_ctx* c, int64_t max_triples);
+void decoder_free(rgcn_ctx* c);
+rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N);
+rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param);
+rgcn_status optimizer_step(rgcn_ctx* c);
+void optimizer_free(rgcn_ctx* c);
 
 // ---- comm.cpp (RCCL via dlopen)
 rgcn_status comm_unique_id(uint8_t id[128]);

@@ -1,0 +1,124 @@
+"""'Next' rows f1/f2 on the GPU: device DistMult decoder (loss, regulariser, gradients), clip + Adam, and the
+whole train step, against the oracle's restatements."""
+import numpy as np
+import pytest
+
+import oracle
+import helpers
+from helpers import assert_close, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+def decoder_batch(rng, triples, V, neg_rate=3, hub=None):
+    pos = triples.copy()
+    neg = np.tile(pos, (neg_rate, 1))
+    side = rng.rand(len(neg)) < 0.5
+    rnd = rng.randint(0, V, len(neg))
+    neg[side, 2] = rnd[side]
+    neg[~side, 0] = rnd[~side]
+    X = np.concatenate([pos, neg]).astype(np.int32)
+    if hub is not None:            # a hub entity with > 256 incidences exercises the long-row workgroups
+        X[: len(X) // 3, 0] = hub
+    Y = np.concatenate([np.ones(len(pos)), np.zeros(len(neg))]).astype(np.float32)
+    return X, Y
+
+
+@pytest.mark.parametrize("V,R,d,nb,E,hub", [(60, 7, 20, 4, 200, None), (120, 9, 40, 8, 600, 5),
+                                            (50, 5, 9, 3, 100, None)])
+def test_device_decoder_matches_oracle(native, V, R, d, nb, E, hub):
+    L = 2
+    params, triples, masks, _ = make_case(V, R, d, L, "block", nb, E, seed=E)
+    rng = np.random.RandomState(1)
+    X, Y = decoder_batch(rng, triples, V, hub=hub)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, masks=masks)
+        codes = eng.codes()
+        eng.decoder_reserve(len(X))
+        xd, yd = eng.to_device(X), eng.to_device(Y)
+        eng.decoder_loss_backward_device(xd, yd, len(X), 0.01)
+        loss, dcodes, dwrel = eng.loss(), eng.dcodes(), eng.get_grad("W_relation")
+        eng.backward_from_decoder()
+        grads = eng.get_grads()
+        xd.free(); yd.free()
+    finally:
+        eng.close()
+    oloss, odcodes, odwrel = oracle.distmult_loss_and_grads(codes, params["W_relation"], X, Y, 0.01)
+    assert abs(loss - oloss) <= 2e-5 * max(1.0, abs(oloss))
+    assert_close(dcodes, odcodes, rel=2e-4, name="dcodes")
+    assert_close(dwrel, odwrel, rel=2e-4, name="dW_relation")
+    assert not dwrel[R:].any()
+    # and the encoder backward fed from the device-resident dcodes
+    acts = oracle.encoder_forward(params, triples, V, L, "block", mode="train", dropout_masks=masks)
+    og = oracle.encoder_backward(params, triples, V, L, "block", acts, odcodes, mode="train", dropout_masks=masks)
+    for k in og:
+        assert_close(grads[k], og[k], rel=5e-4, name=k)
+
+
+def numpy_clip_adam(params, grads, names, lr, b1, b2, eps, max_norm, steps_state):
+    gn = np.sqrt(sum(float(np.sum(grads[n].astype(np.float64) ** 2)) for n in names))
+    scale = max_norm / max(gn, max_norm)
+    t = steps_state["t"] = steps_state.get("t", 0) + 1
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    out = {}
+    for n in names:
+        g = grads[n] * np.float32(scale)
+        m = steps_state.setdefault("m_" + n, np.zeros_like(g))
+        v = steps_state.setdefault("v_" + n, np.zeros_like(g))
+        m[...] = b1 * m + (1 - b1) * g
+        v[...] = b2 * v + (1 - b2) * g * g
+        out[n] = params[n] - np.float32(lr_t) * m / (np.sqrt(v) + np.float32(eps))
+    return out, gn
+
+
+@pytest.mark.parametrize("kind,nb", [("block", 4), ("basis", 2)])
+def test_train_step_device_with_clip_and_adam(native, kind, nb):
+    V, R, d, L, E = 80, 8, 20, 2, 300
+    params, triples, _, _ = make_case(V, R, d, L, kind, nb, E, seed=77)
+    rng = np.random.RandomState(2)
+    X, Y = decoder_batch(rng, triples, V)
+    names = [n for n in oracle.weight_names(kind, L) if not (n.startswith("b") and n != "b_emb")]
+    eng = native.Engine(V, R, d, L, kind, nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.decoder_reserve(len(X))
+        eng.optimizer_config(lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0)
+        td, xd, yd = eng.to_device(triples), eng.to_device(X), eng.to_device(Y)
+        state = {}
+        cur = {k: v.copy() for k, v in params.items()}
+        for step in range(3):
+            eng.train_step_device(td, E, xd, yd, len(X), seed=500 + step, reg_param=0.01)
+            loss = eng.loss()
+            masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
+            grads = eng.get_grads()
+            new = {n: eng.get_param(n) for n in eng.param_names}
+            # replay on the oracle from the SAME pre-step weights
+            acts = oracle.encoder_forward(cur, triples, V, L, kind, mode="train", dropout_masks=masks)
+            oloss, odc, odw = oracle.distmult_loss_and_grads(acts[-1], cur["W_relation"], X, Y, 0.01)
+            og = oracle.encoder_backward(cur, triples, V, L, kind, acts, odc, mode="train", dropout_masks=masks)
+            og["W_relation"] = odw
+            assert abs(loss - oloss) <= 5e-5 * max(1.0, abs(oloss)), (step, loss, oloss)
+            for n in names:
+                assert_close(grads[n], og[n], rel=1e-3, name="step %d grad %s" % (step, n))
+            # the device update, replayed in numpy from the DEVICE gradients (isolates the optimizer)
+            expect, gn = numpy_clip_adam(cur, grads, names, 0.01, 0.9, 0.999, 1e-8, 1.0, state)
+            for n in names:
+                assert_close(new[n], expect[n], rel=2e-5, spike=2e-4, name="step %d weight %s" % (step, n))
+            for n in eng.param_names:
+                if n not in names:
+                    np.testing.assert_array_equal(new[n], cur[n])          # unused biases never move
+            cur = new
+        for b in (td, xd, yd):
+            b.free()
+    finally:
+        eng.close()
