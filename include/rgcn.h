@@ -238,6 +238,18 @@ rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises *
  * With overlap off every kernel runs alone on the main stream: per-kernel durations are exclusive. */
 rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
 
+/* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.
+ *   6 : (default) every fp32 operand is split exactly into three bf16 numbers hi + mid + lo (round to
+ *       nearest + exact residual, twice) and the product is accumulated in fp32 from 6 of the 9 partial
+ *       products on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16); the three dropped ones (mid*lo,
+ *       lo*mid, lo*lo) are below 2^-26 of |a||b| per product, a quarter of one fp32 rounding.  Measured
+ *       error against float64 equals the fp32-MFMA path's (tests/test_gpu_parity.py::test_gemm_modes).
+ *   9 : all 9 partial products - the products of exact fp32 arithmetic in another summation order
+ *   0 : fp32 MFMA (v_mfma_f32_32x32x2_f32), 1/16 of the bf16 rate on gfx950
+ *   3 : hi*hi, hi*mid, mid*hi only (about 2^-17; NOT fp32 - experiments only)
+ * RGCN_GEMM_MODE in the environment overrides the default at create. */
+rgcn_status rgcn_set_gemm_mode(rgcn_ctx* ctx, int32_t mode);
+
 /* Per-kernel profile: when enabled every launch is bracketed by HIP events on the context's stream.
  * Records aggregate by kernel name; alg_bytes / alg_flops are the ALGORITHMIC bytes / flops of the
  * launches ("roofline accounting"), summed over calls. */

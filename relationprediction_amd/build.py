@@ -21,10 +21,16 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librgcn.so")
 ARCH = "gfx950"
-SOURCES = ["rgcn_api.hip", "graph_prep.hip", "gemm_f32.hip", "block_msgs.hip", "basis.hip",
+SOURCES = ["rgcn_api.hip", "graph_prep.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h")]
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# No packed-FP32 VALU instructions anywhere in the library: on gfx950 a v_pk_fma_f32 (and kin) issued
+# by a wave that shares a CU with waves issuing v_mfma_f32_32x32x16_bf16 returns wrong low halves
+# (reproducer: tools/mfma_corun.hip).  The encoder runs its HBM-bound kernels on side
+# streams beside the bf16-split GEMM, so the feature is switched off for the device compile (the host
+# pass prints "not a recognized feature" and ignores it) and the linked code objects are checked.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 
 
 def _hipcc():
@@ -41,6 +47,39 @@ def _digest(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def _llvm_objdump():
+    for cand in ("/opt/rocm/lib/llvm/bin/llvm-objdump", shutil.which("llvm-objdump")):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def check_no_packed_fp32(lib=None):
+    """Disassemble the gfx950 code objects of the library; raise if any packed-FP32 arithmetic is in them."""
+    import glob
+    import re
+    import tempfile
+    lib = lib or LIB
+    objdump = _llvm_objdump()
+    if objdump is None:
+        raise RuntimeError("llvm-objdump not found: cannot verify the library is free of packed-FP32 ops")
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, copy)
+        subprocess.run([objdump, "--offloading", copy], capture_output=True, text=True, cwd=tmp, check=True)
+        bad = []
+        objs = glob.glob(copy + ".*amdgcn*")
+        if not objs:
+            raise RuntimeError("no device code objects found in " + lib)
+        for co in objs:
+            r = subprocess.run([objdump, "-d", co], capture_output=True, text=True, check=True)
+            bad += re.findall(r"v_pk_(?:fma|mul|add)_f32", r.stdout)
+        if bad:
+            raise RuntimeError("librgcn.so contains %d packed-FP32 instructions (%s): they are unsafe beside the "
+                               "bf16-split GEMM" % (len(bad), ", ".join(sorted(set(bad)))))
+    return True
 
 
 def build(force=False, verbose=False):
@@ -79,6 +118,7 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        check_no_packed_fp32(LIB)
     return LIB
 
 

@@ -333,7 +333,10 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   g.vecC = (epi && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
   {
     ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * N * K);
-    switch (variant) {
+    if (c->gemm_mode != 0) {
+      RGCN_HIP(c, gemm_bf16x3_launch(c, c->gemm_mode, a_kc, b_kc, vec, M, N, K, A, lda, B, ldb, g.C, g.ldc,
+                                     g.k_per_split, g.splits, g.swizzle, g.vecC));
+    } else switch (variant) {
       case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
       case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
       default: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;

@@ -245,6 +245,9 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   {
     const char* e = getenv("RGCN_STREAMS");
     c->use_aux = !(e && atoi(e) == 0);
+    const char* m = getenv("RGCN_GEMM_MODE");
+    const int mode = m ? atoi(m) : 6;
+    c->gemm_mode = (mode == 0 || mode == 3 || mode == 6 || mode == 9) ? mode : 6;
   }
   RGCN_HIP(c, hipEventCreate(&c->t0));
   RGCN_HIP(c, hipEventCreate(&c->t1));
@@ -958,6 +961,13 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
   RGCN_NEED(c);
   RGCN_TRY(sync_all(c));
   c->use_aux = on != 0;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_set_gemm_mode(rgcn_ctx* c, int32_t mode) {
+  RGCN_NEED(c);
+  if (mode != 0 && mode != 3 && mode != 6 && mode != 9) RGCN_FAIL(c, RGCN_ERR_INVALID, "gemm mode must be 0, 3, 6 or 9");
+  c->gemm_mode = mode;
   return RGCN_OK;
 }
 

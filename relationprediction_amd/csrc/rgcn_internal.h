@@ -223,6 +223,7 @@ struct rgcn_ctx {
   rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
   hipStream_t pf_stream = nullptr;       // stream of rgcn_prefetch_graph_device
   int chunk = 48;                        // messages per relation chunk
+  int gemm_mode = 0;                     // 0: fp32 MFMA; 3/6/9: bf16 split with that many partial products
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
 
   // forward/backward state
@@ -278,6 +279,11 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* triples_dev, int64_t E);
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                      int split_k);
+
+// gemm_bf16x3.hip: the same contraction on the bf16 matrix cores (exact 3-way operand split)
+hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
+                              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                              int k_per_split, int splits, int swizzle, int vecC);
 
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);

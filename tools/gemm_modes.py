@@ -1,0 +1,59 @@
+"""Accuracy (against float64) and speed of the GEMM arithmetic modes (include/rgcn.h rgcn_set_gemm_mode):
+0 = fp32 MFMA, 9 / 6 / 3 = bf16 operand split with that many partial products.  Self-loop shapes.
+Run on the GPU box: python tools/gemm_modes.py [iters]"""
+import os
+import sys
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from relationprediction_amd import _native as nat  # noqa: E402
+
+V, D = 14541, 500
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.RandomState(0)
+forms = {
+    "NN H.W": (False, False, V, D, D),
+    "NT dS.Wt": (False, True, V, D, D),
+    "TN Ht.dS": (True, False, D, D, V),
+}
+eng = nat.Engine(64, 3, 20, 1, "block", 4, max_edges=16)
+if os.environ.get("RGCN_PROBE_ONLY"):
+    # NT form at one and two tiles per CU (mode 6): the lone-workgroup critical path under RGCN_GEMM_ABLATE
+    eng.set_gemm_mode(6)
+    line = "ablate %s:" % os.environ.get("RGCN_GEMM_ABLATE", "0")
+    for M in (8192, 16384):
+        a = rng.normal(0, 1, (M, D)).astype(np.float32)
+        b = rng.normal(0, 0.19, (D, D)).astype(np.float32)
+        line += "  %d tiles %.1f us" % (M // 128 * 4, eng.debug_gemm_time(a, b, trans_b=True, iters=iters) * 1e3)
+    print(line, flush=True)
+    eng.close()
+    sys.exit(0)
+for name, (ta, tb, M, N, K) in forms.items():
+    # activations like the encoder's: relu'd normal mixture for A-side, N(0, 0.19) weights / small grads
+    a = rng.normal(0, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.normal(0, 0.19, (N, K) if tb else (K, N)).astype(np.float32)
+    if name.startswith("NN"):
+        a = np.maximum(a, 0)
+    a64 = (a.T if ta else a).astype(np.float64)
+    b64 = (b.T if tb else b).astype(np.float64)
+    ref = a64 @ b64
+    mag = np.abs(a64) @ np.abs(b64)          # sum |a||b|: the scale fp32 rounding errors live on
+    flops = 2.0 * M * N * K
+    for mode in (0, 9, 6, 3):
+        eng.set_gemm_mode(mode)
+        got = eng.debug_gemm(a, b, trans_a=ta, trans_b=tb).astype(np.float64)
+        err = np.abs(got - ref)
+        ms = eng.debug_gemm_time(a, b, trans_a=ta, trans_b=tb, iters=iters)
+        print("%-9s mode %d: max|err| %.3e  max err/sum|a||b| %.3e  rms rel %.3e   %.1f us  %.1f TF(fp32-equivalent)"
+              % (name, mode, err.max(), (err / mag).max(), np.sqrt((err ** 2).mean() / (ref ** 2).mean()),
+                 ms * 1e3, flops / ms / 1e9), flush=True)
+# occupancy probe: 256 tiles (one per CU) against 512 (two per CU)
+for M in (8192, 16384, 32768):
+    a = rng.normal(0, 1, (M, D)).astype(np.float32)
+    b = rng.normal(0, 0.19, (D, D)).astype(np.float32)
+    line = "tiles %4d:" % (M // 128 * 4)
+    for mode in (0, 6):
+        eng.set_gemm_mode(mode)
+        line += "  mode %d %.1f us" % (mode, eng.debug_gemm_time(a, b, iters=iters) * 1e3)
+    print(line, flush=True)
+eng.close()
