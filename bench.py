@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 PEAK_F32_MFMA_TFS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_BF16_MFMA_TFS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 
 WORKLOADS = {
     # name: (graph fixture | None, V, R, d, L, kind, nb, E_g)   -- BASELINE.json configs[1] is the headline
@@ -48,6 +49,9 @@ def parse_args():
     ap.add_argument("--workload", default="fb237_block", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("RGCN_GEMM_MODE", "6")), choices=[0, 6, 9],
+                    help="arithmetic of the dense contractions (include/rgcn.h rgcn_set_gemm_mode): 6 / 9 = exact "
+                         "bf16 operand split with 6 / 9 partial products on the bf16 matrix cores, 0 = fp32 MFMA")
     return ap.parse_args()
 
 
@@ -140,6 +144,7 @@ def main():
             if pipeline:
                 eng.prefetch_graph_device(graphs[(i + 1) % 2], E_g)
 
+    eng.set_gemm_mode(args.gemm_mode)
     run(args.warmup, 1000)
     barrier()
     t0 = time.perf_counter()
@@ -155,6 +160,24 @@ def main():
             os.remove(rdv_path)
     ms_per_step = wall * 1e3 / args.steps
     value = E_g * args.steps / wall
+
+    # ---- the same step with the dense contractions on the fp32 MFMA (mode 0), for reference
+    fp32_ref = None
+    if args.gemm_mode != 0:
+        n2 = max(10, args.steps // 2)
+        eng.set_gemm_mode(0)
+        run(3, 3000)
+        barrier()
+        t1 = time.perf_counter()
+        run(n2, 4000)
+        eng.sync()
+        barrier()
+        wall2 = time.perf_counter() - t1
+        if world > 1:
+            wall2 = float(allgather_scalar(wall2).max())
+        fp32_ref = {"value": round(E_g * n2 / wall2, 1), "unit": "edges/s", "ms_per_step": round(wall2 * 1e3 / n2, 4),
+                    "steps": n2, "arithmetic": "v_mfma_f32_32x32x2_f32 (rgcn_set_gemm_mode 0)"}
+        eng.set_gemm_mode(args.gemm_mode)
 
     # ---- per-kernel accounting: the same steps again with HIP events around every launch.
     # Pass 1 as timed above (side streams + pipelined prep: durations of co-running kernels overlap and
@@ -180,11 +203,14 @@ def main():
             avg_ms = p["total_ms"] / p["calls"]
             by, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
             t_hbm = by / (PEAK_HBM_GBS * 1e9)
-            t_mfma = fl / (PEAK_F32_MFMA_TFS * 1e12)
+            # flops the matrix cores execute: the split arithmetic issues `terms` bf16 MFMAs per fp32 product
+            terms = args.gemm_mode if args.gemm_mode else 1
+            mfma_peak = PEAK_BF16_MFMA_TFS if args.gemm_mode else PEAK_F32_MFMA_TFS
+            t_mfma = terms * fl / (mfma_peak * 1e12)
             bound = "mfma" if t_mfma > t_hbm else "hbm"
             sec = max(avg_ms, 1e-9) * 1e-3
             if bound == "mfma":
-                ach, peak, unit = fl / sec / 1e12, PEAK_F32_MFMA_TFS, "TFLOP/s"
+                ach, peak, unit = terms * fl / sec / 1e12, mfma_peak, "TFLOP/s"
             else:
                 ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
             kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / args.steps,
@@ -193,6 +219,10 @@ def main():
                             "ms_per_step": round(p["total_ms"] / args.steps, 4),
                             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                             "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
+            if bound == "mfma":
+                kernels[-1]["mfma_dtype"] = "bf16 (x%d exact operand split of fp32)" % terms if args.gemm_mode else "f32"
+                kernels[-1]["executed_flops"] = terms * fl
+                kernels[-1]["fp32_equivalent_tflops"] = round(fl / sec / 1e12, 2)
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/*_traffic.json, FETCH_SIZE doubled per MI355X_MICROARCH.md): not collectable live
         traffic = {}
@@ -203,8 +233,9 @@ def main():
                 traffic = json.load(open(tj[-1]))["kernels"]
         except Exception:  # noqa: BLE001
             traffic = {}
-        alias = {"gemm_self_fwd": "k_gemm_f32<true, false", "gemm_self_dh": "k_gemm_f32<true, true",
-                 "gemm_self_dw": "k_gemm_f32<false, false", "block_msg_fwd": "k_block_msg_fwd",
+        gk = "k_gemm_bf16x3" if args.gemm_mode else "k_gemm_f32"
+        alias = {"gemm_self_fwd": gk + "<true, false", "gemm_self_dh": gk + "<true, true",
+                 "gemm_self_dw": gk + "<false, false", "block_msg_fwd": "k_block_msg_fwd",
                  "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine"}
         for k in kernels:
             pref = alias.get(k["kernel"])
@@ -217,6 +248,9 @@ def main():
                         "avg_us_in_pipeline": k["avg_us_in_pipeline"],
                         "note": "exclusive duration (overlap off); in the pipelined step it co-runs with HBM-bound kernels",
                         "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
+            for extra in ("mfma_dtype", "executed_flops", "fp32_equivalent_tflops"):
+                if extra in k:
+                    roofline[extra] = k[extra]
 
     # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
     cpu = None
@@ -240,7 +274,10 @@ def main():
             "metric": "processed edges/sec (R-GCN forward+backward), FB15k-237 gcn_%s" % kind,
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.gemm_mode == 0 else
+                     "f32 (dense contractions: fp32 operands split exactly into 3 bf16, %d of 9 partial products on the "
+                     "bf16 matrix cores, fp32 accumulation; error vs float64 equal to the fp32 MFMA's)" % args.gemm_mode,
             "data": "real FB15k-237 valid+test graph structure (15,000-edge minibatch per SURVEY 8d), "
                     "reference-distribution random-init weights, synthetic upstream gradient",
             "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
@@ -253,6 +290,7 @@ def main():
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
             "message_edges_per_s": round(2 * L * value, 1),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "fp32_mfma_reference": fp32_ref,
         }
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
