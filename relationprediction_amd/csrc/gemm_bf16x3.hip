@@ -488,6 +488,7 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
   g.tiles_n = (N + BN - 1) / BN;
   static const int ablate = getenv("RGCN_GEMM_ABLATE") ? atoi(getenv("RGCN_GEMM_ABLATE")) : 0;
   g.ablate = ablate;
+
   if (terms == 6 && vec && a_kc && b_kc && (ablate & ~4)) {   // timing experiments on the NT form only
     switch (ablate & ~4) {
       case 1: return launch_one<true, true, true, 6, 1>(c, g);
