@@ -178,6 +178,36 @@ rgcn_status rgcn_decoder_loss_backward_device(rgcn_ctx* ctx, const int32_t* x_de
                                               int64_t num_triples, float regularization_parameter);
 const float* rgcn_dcodes_device(rgcn_ctx* ctx);
 rgcn_status rgcn_get_loss(rgcn_ctx* ctx, double* loss);
+/* ---- minibatch construction on the host ---------------------------------------------
+ * sample_edge_neighborhood of the reference's train loop (code/train.py:133-139 adjacency, :161-198 sampler):
+ * the same random process (vertex ~ free edge ends x touched, then a free incident edge uniformly; uniform
+ * restart over vertices with free edges when nothing touched has any) in O(log V) per pick instead of the
+ * reference's O(V).  Host memory in, host memory out, no context, no GPU.  triples = int32 [n,3] rows
+ * (subject, relation, object) of the training graph; out_edge_ids = int32 [sample_size] distinct row ids.
+ * sample_size > n is an error (the reference crashes there). */
+typedef struct rgcn_sampler rgcn_sampler;
+rgcn_status rgcn_sampler_create(const int32_t* triples, int64_t num_triples, int32_t num_entities,
+                                rgcn_sampler** out);
+void rgcn_sampler_destroy(rgcn_sampler* sampler);
+rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* sampler, int64_t sample_size, uint64_t seed,
+                                           int32_t* out_edge_ids);
+
+/* ---- evaluation: raw and filtered link-prediction ranks -------------------------------
+ * Replaces Model.score_all_subjects / score_all_objects + Scorer.evaluate_mrr + MrrScore.append_line
+ * (code/model.py:59-81, code/decoders/bilinear_diag.py:51-61, code/common/evaluation.py:148-153,349-389).
+ * For every query triple x[i] = (s, r, o): score every entity e as sigmoid(sum_k codes[e,k] (W_relation[r] *
+ * codes[o])[k]) (predict_object = 0: rank the subject) or sigmoid(sum_k (codes[s] * W_relation[r])[k] codes[e,k])
+ * (predict_object = 1) on the codes of the last rgcn_forward, then
+ *   raw_rank[i]      = #{e : score[e] >= score[gold]}
+ *   filtered_rank[i] = raw_rank[i] - #{e in filter_idx[filter_ptr[i] : filter_ptr[i+1]] : score[e] >= score[gold]} + 1
+ * (the filter list holds the known completions of the pair, the gold entity among them).  Comparisons are made
+ * on fp32 sigmoid values as in the reference (saturated scores tie).  Everything is a device pointer;
+ * rgcn_rank_reserve(max_queries) sizes the [max_queries, V] score buffer, longer inputs are chunked. */
+rgcn_status rgcn_rank_reserve(rgcn_ctx* ctx, int64_t max_queries);
+rgcn_status rgcn_rank_device(rgcn_ctx* ctx, const int32_t* x_dev, int64_t num_queries, int32_t predict_object,
+                             const int64_t* filter_ptr_dev, const int32_t* filter_idx_dev, int32_t* raw_rank_dev,
+                             int32_t* filtered_rank_dev);
+
 /* GradientClipping(max_norm) + Adam(lr) of the Converge chain (optimization/tensorflow_backend/
  * algorithms.py:27-42,58-68).  max_grad_norm = 0 disables clipping. */
 rgcn_status rgcn_optimizer_config(rgcn_ctx* ctx, float learning_rate, float beta1, float beta2, float epsilon,

@@ -21,7 +21,7 @@ import numpy as np
 import scipy.sparse as sp
 
 __all__ = [
-    "KIND_BLOCK", "KIND_BASIS", "NORM_INTENDED", "NORM_TF_AS_EXECUTED", "NORM_NONE",
+    "KIND_BLOCK", "KIND_BASIS", "NORM_INTENDED", "NORM_TF_AS_EXECUTED", "NORM_NONE", "distmult_ranks", "sample_edge_neighborhood",
     "glorot_variance", "init_params", "weight_names", "split_graph",
     "incidence_values", "incidence_matrix", "affine_onehot_forward",
     "concat_messages", "basis_messages", "self_loop", "dropout", "combine_messages",
@@ -395,6 +395,64 @@ def distmult_loss_and_grads(codes, W_relation, X, Y, reg_param=0.01):
 
 
 # --------------------------------------------------------------------------- workload builders
+
+def distmult_ranks(codes, W_relation, triples, predict_object, known):
+    """Raw and filtered ranks as the reference computes them: scores against every entity
+    (bilinear_diag.py:51-61: sigmoid of the energies), then MrrScore.append_line (evaluation.py:148-153):
+    raw = #{score >= score[gold]}, filtered = raw - #{known with score >= score[gold]} + 1.
+    ``known`` maps (entity, relation) -> list of completing entities (Scorer.known_object_triples for
+    predict_object, known_subject_triples otherwise; evaluation.py:232-270).  The sigmoid is evaluated in
+    float64 and rounded once to float32, then compared in float32 (saturated scores tie, as in TF)."""
+    codes = np.asarray(codes, dtype=F32)
+    rel = np.asarray(W_relation, dtype=F32)
+    raw, filt = [], []
+    for s, r, o in np.asarray(triples):
+        if predict_object:
+            q, gold, key = codes[s] * rel[r], o, (s, r)
+        else:
+            q, gold, key = rel[r] * codes[o], s, (o, r)
+        energies = (codes @ q).astype(F32)
+        with np.errstate(over="ignore"):
+            scores = (1.0 / (1.0 + np.exp(-energies.astype(np.float64)))).astype(F32)
+        g = scores[gold]
+        n_raw = int(np.sum(scores >= g))
+        idx = np.asarray(known[key], dtype=np.int64)
+        raw.append(n_raw)
+        filt.append(n_raw - int(np.sum(scores[idx] >= g)) + 1)
+    return np.asarray(raw, dtype=np.int32), np.asarray(filt, dtype=np.int32)
+
+
+def sample_edge_neighborhood(triples, num_entities, sample_size, rng):
+    """The reference's neighbourhood edge sampler, step for step (code/train.py:133-139, 161-198): adjacency
+    entries [edge, other vertex] per vertex, `sample_counts` = free edge ends, `seen` = touched; a vertex is
+    drawn with p ~ sample_counts * seen (uniform over vertices with free ends when that is all zero), then
+    adjacency entries of it uniformly until one is not picked yet.  O(V) per pick — small graphs only."""
+    triples = np.asarray(triples)
+    adj = [[] for _ in range(num_entities)]
+    for i, (s, _, o) in enumerate(triples):
+        adj[s].append((i, o))
+        adj[o].append((i, s))
+    sample_counts = np.array([len(a) for a in adj], dtype=np.int64)
+    picked = np.zeros(len(triples), dtype=bool)
+    seen = np.zeros(num_entities, dtype=bool)
+    edges = np.zeros(sample_size, dtype=np.int32)
+    for i in range(sample_size):
+        weights = sample_counts * seen
+        if weights.sum() == 0:
+            weights = np.ones_like(weights)
+            weights[sample_counts == 0] = 0
+        v = rng.choice(num_entities, p=weights / weights.sum())
+        seen[v] = True
+        e, other = adj[v][rng.randint(len(adj[v]))]
+        while picked[e]:
+            e, other = adj[v][rng.randint(len(adj[v]))]
+        edges[i] = e
+        picked[e] = True
+        sample_counts[v] -= 1
+        sample_counts[other] -= 1
+        seen[other] = True
+    return edges
+
 
 def sample_minibatch_graph(triples, graph_batch_size, graph_split_size, rng):
     """Shape of what t_func feeds the encoder (code/train.py:227-238): pick ``graph_batch_size``

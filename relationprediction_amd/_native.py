@@ -69,6 +69,11 @@ _SIGS = {
     "rgcn_dcodes_device": (_P, [_P]),
     "rgcn_get_loss": (C.c_int32, [_P, C.POINTER(C.c_double)]),
     "rgcn_optimizer_config": (C.c_int32, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rgcn_sampler_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    "rgcn_sampler_destroy": (None, [_P]),
+    "rgcn_sampler_edge_neighborhood": (C.c_int32, [_P, C.c_int64, C.c_uint64, _P]),
+    "rgcn_rank_reserve": (C.c_int32, [_P, C.c_int64]),
+    "rgcn_rank_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "rgcn_optimizer_step": (C.c_int32, [_P]),
     "rgcn_train_step_device": (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint64, C.c_float]),
     "rgcn_prefetch_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
@@ -163,6 +168,35 @@ class DeviceBuffer:
         self.ptr = None
 
 
+class NeighborhoodSampler:
+    """sample_edge_neighborhood of the reference's train loop (code/train.py:161-198) in O(log V) per pick
+    (include/rgcn.h rgcn_sampler_*).  Host only: needs the library, not a GPU."""
+
+    def __init__(self, triples, num_entities):
+        self.lib = load_library()
+        t = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 3)
+        self.n = len(t)
+        h = C.c_void_p()
+        st = self.lib.rgcn_sampler_create(_ptr(t), self.n, int(num_entities), C.byref(h))
+        if st != 0:
+            raise RgcnError(st, "rgcn_sampler_create (ids out of range or empty graph)")
+        self.handle = h
+
+    def sample(self, sample_size, seed):
+        out = np.empty(int(sample_size), dtype=np.int32)
+        st = self.lib.rgcn_sampler_edge_neighborhood(self.handle, int(sample_size), C.c_uint64(int(seed)), _ptr(out))
+        if st != 0:
+            raise RgcnError(st, "rgcn_sampler_edge_neighborhood (sample_size %d of %d edges)" % (sample_size, self.n))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.rgcn_sampler_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
 class Engine:
     """One rgcn_ctx: the encoder (input layer + L relational graph-convolution layers) on one GPU."""
 
@@ -192,6 +226,7 @@ class Engine:
             raise RgcnError(st, (self.lib.rgcn_last_error(None) or b"").decode())
         self.ctx = ctx
         self.V, self.R, self.d, self.L = cfg.num_entities, cfg.num_relations, cfg.dim, cfg.num_layers
+        self.max_edges = int(cfg.max_edges)
         self.param_names, self.param_shapes = [], []
         for i in range(self.lib.rgcn_param_count(self.ctx)):
             name = C.create_string_buffer(64)
@@ -339,6 +374,29 @@ class Engine:
         self._check(self.lib.rgcn_get_loss(self.ctx, C.byref(v)))
         return float(v.value)
 
+    def rank_reserve(self, max_queries):
+        self._check(self.lib.rgcn_rank_reserve(self.ctx, int(max_queries)))
+
+    def ranks(self, triples, predict_object, filter_ptr, filter_idx):
+        """Raw and filtered ranks (include/rgcn.h rgcn_rank_device) of the gold subject / object of every
+        query triple on the codes of the last forward.  filter_ptr int64 [N+1], filter_idx int32 [nnz]."""
+        x = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 3)
+        n = len(x)
+        if n == 0:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        fp = np.ascontiguousarray(filter_ptr, dtype=np.int64)
+        fi = np.ascontiguousarray(filter_idx, dtype=np.int32)
+        assert fp.shape == (n + 1,) and fp[-1] == len(fi)
+        bufs = [self.to_device(x), self.to_device(fp), self.to_device(fi if len(fi) else np.zeros(1, np.int32)),
+                DeviceBuffer(self, 4 * n), DeviceBuffer(self, 4 * n)]
+        try:
+            self._check(self.lib.rgcn_rank_device(self.ctx, bufs[0].ptr, n, 1 if predict_object else 0, bufs[1].ptr,
+                                                  bufs[2].ptr, bufs[3].ptr, bufs[4].ptr))
+            return bufs[3].download(np.int32, (n,)), bufs[4].download(np.int32, (n,))
+        finally:
+            for b in bufs:
+                b.free()
+
     def optimizer_config(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0):
         self._check(self.lib.rgcn_optimizer_config(self.ctx, lr, beta1, beta2, eps, max_grad_norm))
 
@@ -411,6 +469,12 @@ class Engine:
     # -- device memory / timing / profile
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def copy_to_device(self, buf, arr):
+        """Upload into the front of an existing (possibly larger) device buffer."""
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= buf.nbytes
+        self._check(self.lib.rgcn_copy_to_device(self.ctx, buf.ptr, _ptr(arr), arr.nbytes))
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -167,6 +167,7 @@ static void free_all(rgcn_ctx* c) {
   auto F = [](void* p) { if (p) (void)hipFree(p); };
   decoder_free(c);
   optimizer_free(c);
+  rank_free(c);
   F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb); F(c->w_rel); F(c->g_rel);
   for (LayerBufs& lb : c->layers) {
     F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);
@@ -774,6 +775,26 @@ rgcn_status rgcn_get_loss(rgcn_ctx* c, double* loss) {
   if (!c->dec.loss_valid) RGCN_FAIL(c, RGCN_ERR_STATE, "no decoder pass has run");
   RGCN_TRY(check_dev_flag(c));
   return to_host(c, loss, c->dec.loss, sizeof(double));
+}
+
+rgcn_status rgcn_rank_reserve(rgcn_ctx* c, int64_t max_queries) {
+  RGCN_NEED(c);
+  if (max_queries <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "max_queries must be positive");
+  RGCN_TRY(sync_all(c));
+  return rank_reserve(c, max_queries);
+}
+
+rgcn_status rgcn_rank_device(rgcn_ctx* c, const int32_t* x_dev, int64_t n, int32_t predict_object,
+                             const int64_t* filter_ptr_dev, const int32_t* filter_idx_dev, int32_t* raw_rank_dev,
+                             int32_t* filtered_rank_dev) {
+  RGCN_NEED(c);
+  if (n < 0 || (n > 0 && (!x_dev || !filter_ptr_dev || !raw_rank_dev || !filtered_rank_dev)))
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_rank_device needs a completed rgcn_forward (test mode on the full graph)");
+  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "ranking on a sharded context (not built yet)");
+  if (c->rank_max <= 0) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_rank_reserve first");
+  if (n == 0) return RGCN_OK;
+  return rank_compute(c, x_dev, n, predict_object ? 1 : 0, filter_ptr_dev, filter_idx_dev, raw_rank_dev, filtered_rank_dev);
 }
 
 rgcn_status rgcn_optimizer_config(rgcn_ctx* c, float lr, float beta1, float beta2, float eps, float max_grad_norm) {

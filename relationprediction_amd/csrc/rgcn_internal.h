@@ -234,6 +234,9 @@ struct rgcn_ctx {
   const float* bwd_D = nullptr;          // D_l of the backward layer in flight
   const float* bwd_dS = nullptr;         // dS_l = D_l * dropout_l
   int bwd_layer = 0;                     // next layer the backward pass will process (L..1, 0 = done)
+  float *rank_q = nullptr, *rank_s = nullptr;   // ranking: query rows [max,d], energies [max,V]
+  int32_t* rank_bad = nullptr;
+  int64_t rank_max = 0;
   float* dcodes_own = nullptr;           // [V,d] staging for the host variant of backward
 
   // comm
@@ -334,6 +337,11 @@ void decoder_free(rgcn_ctx* c);
 rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N);
 rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param);
 rgcn_status optimizer_step(rgcn_ctx* c);
+// ---- ranking.hip
+rgcn_status rank_reserve(rgcn_ctx* c, int64_t max_queries);
+void rank_free(rgcn_ctx* c);
+rgcn_status rank_compute(rgcn_ctx* c, const int32_t* X_dev, int64_t N, int predict_object, const int64_t* filt_ptr,
+                         const int32_t* filt_idx, int32_t* raw_out, int32_t* filt_out);
 void optimizer_free(rgcn_ctx* c);
 
 // ---- comm.cpp (RCCL via dlopen)

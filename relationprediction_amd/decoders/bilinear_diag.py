@@ -4,9 +4,10 @@ energy = sum_k e1_k r_k e2_k over the gathered codes (:18-21,30); loss = mean si
 with pos_weight forced to 1 (:32-34); regulariser = RegularizationParameter x (mean(e1^2) + mean(r^2) +
 mean(e2^2)) (:63-69); scoring against every entity as `sigmoid(codes . (r*e2)^T)` (:46-61).
 
-BASELINE.json: "the DistMult decoder and negative-sampling loss stay as-is" -- the decoder is the
-boundary CONSUMER of the accelerated encoder, evaluated here on the host in numpy; a fused HIP
-score+loss+gradient kernel is the first 'next' row.
+BASELINE.json: "the DistMult decoder and negative-sampling loss stay as-is".  The call-by-call surface of
+the reference (get_loss, predict_*, backward) is evaluated eagerly in numpy on codes the engine computed;
+the training driver and the scorer use the fused device paths below (csrc/decoder.hip,
+csrc/optimizer.hip, csrc/ranking.hip).
 """
 import numpy as np
 
@@ -68,6 +69,27 @@ class BilinearDiag(Model):
         e1s, rs, e2s = self.compute_codes(mode='test')
         all_object_codes = self.next_component.get_all_object_codes(mode='test')
         return _sigmoid(np.matmul(e1s * rs, all_object_codes.T))
+
+    # ---- fused device paths: what the training driver and the scorer use (the eager numpy methods above
+    # keep the reference's call-by-call surface and serve as their small-size cross-check)
+    def configure_device_optimizer(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, max_grad_norm=0.0):
+        self.next_component.get_runtime().configure_optimizer(learning_rate, beta1, beta2, epsilon, max_grad_norm)
+
+    def device_train_step(self, graph_edges, x, y, seed):
+        """loss + regularisation, all gradients, clip and Adam in one asynchronous device step."""
+        self.next_component.get_runtime().train_step(graph_edges, x, y, self.regularization_parameter, seed)
+
+    def device_loss(self):
+        return self.next_component.get_runtime().loss()
+
+    def device_ranks(self, graph, triplets, predict_object, filter_ptr, filter_idx):
+        """Ranks of the gold subjects / objects of `triplets` against every entity, codes from a test-mode
+        pass over `graph` (what score_all_subjects / score_all_objects + MrrScore.append_line compute)."""
+        variables = self.get_test_input_variables()
+        if getattr(self, '_ranks_graph', None) is not graph or variables[0].value is None:
+            variables[0].feed(graph)          # re-encoded only when the graph or the weights changed
+            self._ranks_graph = graph
+        return self.next_component.get_runtime().ranks(triplets, predict_object, filter_ptr, filter_idx)
 
     def backward(self, upstream=None):
         """d(loss + regularisation)/d(codes, W_relation), then down the chain."""

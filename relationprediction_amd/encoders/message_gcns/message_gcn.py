@@ -59,6 +59,9 @@ class MessageGcn(Model):
         if not hasattr(rep, '_top_gcn'):
             rep._top_gcn = self
 
+    def get_runtime(self):
+        return self._runtime()
+
     # ---- reference surface
     def get_all_codes(self, mode='train'):
         collected_messages = self.compute_vertex_embeddings(mode=mode)

@@ -24,10 +24,24 @@ class RelationEmbedding(Model):
     def local_get_weights(self):
         return [self.W_relation]
 
+    def _bind(self):
+        """W_relation lives in the engine (last parameter of rgcn_param_info) so that the device decoder and
+        the device optimizer see it; bound on first use, when the stack's runtime exists."""
+        if not getattr(self, '_bound', False):
+            rt = self.next_component.get_runtime()
+            self.W_relation.bind(*rt._accessors("W_relation"))
+            self._bound = True
+
+    def get_runtime(self):
+        self._bind()
+        return self.next_component.get_runtime()
+
     def get_all_codes(self, mode='train'):
+        self._bind()
         codes = self.next_component.get_all_codes(mode=mode)
         return codes[0], self.W_relation.value(), codes[2]
 
     def backward(self, upstream):
+        self._bind()
         dcodes, d_relation = upstream
         return self.next_component.backward(dcodes) + [d_relation]

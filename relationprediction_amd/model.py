@@ -176,6 +176,22 @@ class Model(object):
     def get_graph(self):
         return self.__delegate__('get_graph')
 
+    def configure_device_optimizer(self, *args, **kwargs):
+        return self.__delegate__('configure_device_optimizer', *args, **kwargs)
+
+    def device_train_step(self, *args):
+        return self.__delegate__('device_train_step', *args)
+
+    def device_loss(self):
+        return self.__delegate__('device_loss')
+
+    def device_ranks(self, *args):
+        return self.__delegate__('device_ranks', *args)
+
+    def get_runtime(self):
+        """The EncoderRuntime (one HIP engine context) the chain's graph-convolution stack runs on."""
+        return self.__delegate__('get_runtime')
+
     def needs_graph(self):
         return False if self.next_component is None else self.next_component.needs_graph()
 
@@ -186,10 +202,10 @@ class Model(object):
         return self.__delegate__('backward', upstream)
 
     # ---- delegation primitives (same semantics as model.py:147-182)
-    def __delegate__(self, name, *args):
+    def __delegate__(self, name, *args, **kwargs):
         if self.next_component is None:
             return None
-        return getattr(self.next_component, name)(*args)
+        return getattr(self.next_component, name)(*args, **kwargs)
 
     def __local_run_delegate__(self, name, *args):
         local = getattr(self, 'local_' + name, None)

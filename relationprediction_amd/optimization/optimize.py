@@ -1,0 +1,272 @@
+"""Training loop ("Converge", reference: code/optimization/optimize.py + shared/algorithms.py +
+tensorflow_backend/algorithms.py) on top of the fused device train step.
+
+The reference composes the loop from a stack of components, each wrapping the next: data flows down
+(`next_batch`, `process_data`), the loss flows back up (`postprocess`), and two of them (GradientClipping, Adam)
+rewrite the TF gradient / update ops.  The same components exist here with the same parameters and the same
+reporting / stopping behaviour; clipping and Adam become the configuration of the device optimizer
+(rgcn_optimizer_config) and `update_from_batch` is ONE asynchronous device call (rgcn_train_step_device).
+
+One deliberate reordering: the host work of the NEXT batch (neighbourhood sampling, negative sampling) is
+done while the GPU runs the current step, and the loss is fetched afterwards; per iteration the reference's order
+`process_data -> update -> postprocess` is kept, batch i+1 is merely drawn before postprocess(i) runs."""
+import random
+
+import numpy as np
+
+
+class IOptimizer(object):
+    next_component = None
+    iteration = 0
+    validation_data = None
+    training_data = None
+
+    def __init__(self, next_component, parameters):
+        self.next_component = next_component
+        for k, v in parameters.items():
+            setattr(self, k, v)
+
+    def valid(self):
+        return True
+
+    def verify(self):
+        return self.valid() and (self.next_component is None or self.next_component.verify())
+
+    def process_data(self, data):
+        return self.next_component.process_data(data)
+
+    def postprocess(self, loss):
+        return self.next_component.postprocess(loss) if self.next_component is not None else 'continue'
+
+    def set_iteration(self, iteration):
+        self.iteration = iteration
+        if self.next_component is not None:
+            self.next_component.set_iteration(iteration)
+
+    def next_batch(self):
+        return self.next_component.next_batch()
+
+    def set_validation_data(self, validation_data):
+        self.validation_data = validation_data
+        if self.next_component is not None:
+            self.next_component.set_validation_data(validation_data)
+
+    def set_training_data(self, training_data):
+        self.training_data = training_data
+        if self.next_component is not None:
+            self.next_component.set_training_data(training_data)
+
+    def configure_device(self, cfg):
+        """Collect what the device optimizer needs (replaces process_gradient/update_function)."""
+        if self.next_component is not None:
+            self.next_component.configure_device(cfg)
+
+
+class BaseOptimizer(IOptimizer):
+    def __init__(self):
+        self.next_component = None
+
+    def next_batch(self):
+        return self.training_data
+
+    def process_data(self, data):
+        return data
+
+    def postprocess(self, loss):
+        return 'continue'
+
+
+class IterationCounter(IOptimizer):            # shared/algorithms.py:5-19
+    max_iterations = None
+    iterations = 0
+
+    def valid(self):
+        return self.max_iterations is not None
+
+    def next_batch(self):
+        if self.iterations < self.max_iterations:
+            self.iterations += 1
+            return self.next_component.next_batch()
+        return None
+
+
+class Minibatches(IOptimizer):                 # shared/algorithms.py:21-48 (random sampling branch)
+    batch_size = None
+    contiguous_sampling = None
+
+    def valid(self):
+        return self.batch_size is not None and self.contiguous_sampling is False
+
+    def next_batch(self):
+        data = self.next_component.next_batch()
+        sample = random.sample(range(len(data)), self.batch_size)
+        return [data[i] for i in sample]
+
+
+class SampleTransformer(IOptimizer):           # shared/algorithms.py:51-60
+    transform_function = None
+
+    def valid(self):
+        return self.transform_function is not None
+
+    def process_data(self, training_data):
+        return self.transform_function(self.next_component.process_data(training_data))
+
+
+class GradientClipping(IOptimizer):            # tensorflow_backend/algorithms.py:58-68 (clip_by_global_norm)
+    max_norm = None
+
+    def valid(self):
+        return self.max_norm is not None
+
+    def configure_device(self, cfg):
+        cfg['max_grad_norm'] = float(self.max_norm)
+        IOptimizer.configure_device(self, cfg)
+
+
+class Adam(IOptimizer):                        # tensorflow_backend/algorithms.py:27-42
+    learning_rate = None
+    historical_moment_weight = 0.9             # beta1
+    historical_second_moment_weight = 0.999    # beta2
+    epsilon = 1e-8                             # tf.train.AdamOptimizer default
+
+    def valid(self):
+        return self.learning_rate is not None
+
+    def configure_device(self, cfg):
+        cfg.update(learning_rate=float(self.learning_rate), beta1=float(self.historical_moment_weight),
+                   beta2=float(self.historical_second_moment_weight), epsilon=float(self.epsilon))
+        IOptimizer.configure_device(self, cfg)
+
+
+class AdditionalOp(IOptimizer):                # TF update ops of variational layers: none in scope
+    op = None
+
+
+class ModelSaver(IOptimizer):                  # shared/algorithms.py:62-80
+    model_path = None
+    save_function = None
+    save_every_n = 1
+
+    def valid(self):
+        return self.model_path is not None and self.save_function is not None
+
+    def postprocess(self, loss):
+        value_of_next = self.next_component.postprocess(loss)
+        if value_of_next == 'stop':
+            return 'stop'
+        if self.iteration % self.save_every_n == 0:
+            self.save_function(self.model_path)
+        return value_of_next
+
+
+class TrainLossReporter(IOptimizer):           # shared/algorithms.py:83-115
+    evaluate_every_n = 1
+    cummulative_loss = 0
+
+    def postprocess(self, loss):
+        value_of_next = self.next_component.postprocess(loss)
+        if value_of_next == 'stop':
+            return 'stop'
+        self.cummulative_loss += loss
+        if self.iteration == 1:
+            self.cummulative_loss = 0
+            print("Initial loss: " + str(loss))
+            return value_of_next
+        if self.iteration % self.evaluate_every_n == 1:
+            average_loss = self.cummulative_loss / float(self.evaluate_every_n)
+            self.cummulative_loss = 0
+            print("Average train loss for iteration " + str(self.iteration - self.evaluate_every_n) + "-"
+                  + str(self.iteration - 1) + ": " + str(average_loss))
+        return value_of_next
+
+
+class EarlyStopper(IOptimizer):                # shared/algorithms.py:118-159
+    criteria = None
+    evaluate_every_n = 1
+    previous_validation_score = None
+    burnin = 0
+    scoring_function = None
+    comparator = None
+
+    def valid(self):
+        if self.criteria != 'score_validation_data':
+            return False
+        return self.scoring_function is not None and self.comparator is not None and self.evaluate_every_n is not None
+
+    def postprocess(self, loss):
+        value_of_next = self.next_component.postprocess(loss)
+        if value_of_next == 'stop':
+            return 'stop'
+        if self.iteration % self.evaluate_every_n == 0:
+            validation_score = self.scoring_function(self.validation_data)
+            print("Tested validation score at iteration " + str(self.iteration) + ". Result: " + str(validation_score))
+            if self.previous_validation_score is not None and \
+                    not self.comparator(validation_score, self.previous_validation_score):
+                if self.iteration > self.burnin:
+                    print("Stopping criterion reached.")
+                    return 'stop'
+                print("Ignoring criterion while in burn-in phase.")
+            self.previous_validation_score = validation_score
+        return value_of_next
+
+
+COMPONENTS = {c.__name__: c for c in (IterationCounter, Minibatches, SampleTransformer, GradientClipping, Adam,
+                                      AdditionalOp, ModelSaver, TrainLossReporter, EarlyStopper)}
+
+
+def build_stack(parameters):
+    """The reference's __construct_optimizer (optimize.py:203-215): every pair wraps what was built so far, so
+    the LAST pair of the list is the outermost component and, because each `postprocess` runs its inner
+    neighbour first, the reporting order is TrainLossReporter, EarlyStopper, ModelSaver."""
+    stack = BaseOptimizer()
+    for name, params in parameters:
+        if name not in COMPONENTS:
+            raise NotImplementedError("optimizer component '%s' (only Adam is built as Algorithm.Name)" % name)
+        stack = COMPONENTS[name](stack, params)
+    if not stack.verify():
+        raise ValueError("optimizer parameters do not describe a valid stack")
+    return stack
+
+
+class HipOptimizer(object):
+    """TensorflowOptimizer's role (optimize.py:42-90) on the device train step."""
+
+    def __init__(self, stack, model):
+        self.stack = stack
+        self.model = model
+        cfg = {}
+        stack.configure_device(cfg)
+        if 'learning_rate' not in cfg:
+            raise ValueError("the optimizer stack has no Algorithm")
+        model.configure_device_optimizer(cfg['learning_rate'], cfg['beta1'], cfg['beta2'], cfg['epsilon'],
+                                         cfg.get('max_grad_norm', 0.0))
+
+    def update_from_batch(self, processed_batch, seed):
+        """Enqueue one train step; processed_batch = (graph_edges, X, Y) as the transform function returns."""
+        graph_edges, x, y = processed_batch
+        self.model.device_train_step(graph_edges, x, y, seed)
+
+    def fit(self, training_data, validation_data=None):
+        self.stack.set_training_data(training_data)
+        if validation_data is not None:
+            self.stack.set_validation_data(validation_data)
+        i = 0
+        next_batch = self.stack.next_batch()
+        processed = self.stack.process_data(next_batch) if next_batch is not None else None
+        while processed is not None:
+            i += 1
+            self.stack.set_iteration(i)
+            self.update_from_batch(processed, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+            # host work of the next iteration while the device runs this one
+            next_batch = self.stack.next_batch()
+            processed = self.stack.process_data(next_batch) if next_batch is not None else None
+            train_loss = self.model.device_loss()            # synchronises with the step
+            if self.stack.postprocess(train_loss) == 'stop':
+                print("Stopping training.")
+                break
+        return i
+
+
+def build_hip(model, parameters):
+    return HipOptimizer(build_stack(parameters), model)

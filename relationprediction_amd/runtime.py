@@ -39,6 +39,9 @@ class EncoderRuntime(object):
                                      keep_prob=top.dropout_keep_probability, norm_mode=norm,
                                      max_edges=max_edges, device=device)
         self._state = None        # (graph version, mode) of the activations held by the engine
+        self._dev = {}            # persistent device buffers of the fused train step (name -> DeviceBuffer)
+        self._dec_reserved = 0
+        self._rank_reserved = 0
         self._graph_version = None
         self.weights_version = 0
         self._fwd_weights_version = -1
@@ -80,6 +83,54 @@ class EncoderRuntime(object):
 
     def activation(self, layer):
         return self.engine.activation(layer)
+
+    # ---- fused device paths (include/rgcn.h: rgcn_train_step_device, rgcn_rank_device)
+    def _upload(self, name, arr):
+        """Device copy of `arr` in a persistent buffer that only ever grows."""
+        arr = np.ascontiguousarray(arr)
+        buf = self._dev.get(name)
+        if buf is None or buf.nbytes < arr.nbytes:
+            if buf is not None:
+                buf.free()
+            buf = _native.DeviceBuffer(self.engine, max(arr.nbytes, 16))
+            self._dev[name] = buf
+        if arr.nbytes:
+            self.engine.copy_to_device(buf, arr)
+        return buf
+
+    def configure_optimizer(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, max_grad_norm=0.0):
+        self.engine.optimizer_config(learning_rate, beta1, beta2, epsilon, max_grad_norm)
+
+    def train_step(self, graph_edges, x, y, reg_param, seed):
+        """One update_from_batch (optimize.py:81-88) on the device: graph prep, encoder forward, DistMult
+        loss + gradients, encoder backward, clip + Adam.  Asynchronous; `loss()` synchronises."""
+        g = np.ascontiguousarray(graph_edges, dtype=np.int32).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.int32).reshape(-1, 3)
+        y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+        if len(x) != len(y) or len(x) == 0:
+            raise ValueError("decoder batch: X [N,3] and Y [N] must have the same non-zero length")
+        if len(g) > self.engine.max_edges:
+            raise ValueError("graph batch of %d edges exceeds the context's max_edges %d"
+                             % (len(g), self.engine.max_edges))
+        if len(x) > self._dec_reserved:
+            self.engine.decoder_reserve(len(x))
+            self._dec_reserved = len(x)
+        gd, xd, yd = self._upload("graph", g), self._upload("X", x), self._upload("Y", y)
+        self.engine.train_step_device(gd, len(g), xd, yd, len(x), seed=seed, reg_param=reg_param)
+        self._state = None            # activations now belong to this train step's graph
+        self._graph_version = None
+        self.weights_version += 1
+
+    def loss(self):
+        return self.engine.loss()
+
+    def ranks(self, triples, predict_object, filter_ptr, filter_idx, chunk=2048):
+        """Raw / filtered ranks on the codes of a test-mode forward over the fed graph."""
+        self.forward('test')
+        if self._rank_reserved < chunk:
+            self.engine.rank_reserve(chunk)
+            self._rank_reserved = chunk
+        return self.engine.ranks(triples, predict_object, filter_ptr, filter_idx)
 
     def backward(self, dcodes):
         if self._state is None or self._state[1] != 'train':

@@ -1,0 +1,131 @@
+"""Training driver with the reference's command line (code/train.py):
+
+    python -m relationprediction_amd.train --settings settings/gcn_block.exp --dataset data/FB-Toutanova
+
+Same stages in the same order: read the dataset (:21-47), merge the settings sections (:66-86), build the
+encoder / decoder chain (:92-93), the scorer with validation MRR as early-stopping score (:99-128), the
+minibatch transform (neighbourhood graph batch -> edge dropout split -> negative sampling, :133-247), and the
+Converge loop (:255-284).  What runs where: the chain's components configure ONE HIP engine context; every
+iteration is one asynchronous device step (graph prep, R-GCN forward, DistMult loss, backward, clip, Adam);
+the host draws the next minibatch meanwhile (neighbourhood sampler in librgcn.so, O(log V) per pick); validation
+encodes the training graph once and ranks on the device."""
+import argparse
+
+import numpy as np
+
+from . import _native
+from .common import settings_reader, io, model_builder, optimizer_parameter_parser, evaluation, auxilliaries
+from .optimization.optimize import build_hip
+
+
+def load_dataset(dataset, metric='MRR'):
+    relations_path = dataset + '/relations.dict'
+    entities_path = dataset + '/entities.dict'
+    suffix = '_accuracy' if metric == 'Accuracy' else ''
+    splits = {}
+    for name in ('train', 'valid', 'test'):
+        path = dataset + '/' + name + (suffix if name != 'train' else '') + '.txt'
+        splits[name] = np.array(io.read_triplets_as_list(path, entities_path, relations_path), dtype=np.int32)
+    return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
+
+
+def make_transform(train_triplets, general_settings, encoder, seed_source=np.random):
+    """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y)."""
+    ns = auxilliaries.NegativeSampler(int(general_settings['NegativeSampleRate']), general_settings['EntityCount'])
+    ns.set_known_positives(train_triplets)
+    sampler = None
+    if 'GraphBatchSize' in general_settings:
+        sampler = _native.NeighborhoodSampler(train_triplets, int(general_settings['EntityCount']))
+
+    def t_func(x):
+        arr = np.array(x)
+        if not encoder.needs_graph():
+            return ns.transform(arr)
+        if sampler is not None:
+            graph_batch_size = int(general_settings['GraphBatchSize'])
+            graph_batch_ids = sampler.sample(graph_batch_size, seed_source.randint(0, 2 ** 31 - 1))
+        else:
+            graph_batch_ids = np.arange(arr.shape[0])
+        graph_batch = train_triplets[graph_batch_ids]
+        # edge dropout: the encoder sees a random GraphSplitSize fraction of the batch (exact-k, host side, :235-238)
+        split_size = int(float(general_settings['GraphSplitSize']) * graph_batch.shape[0])
+        graph_split_ids = np.random.choice(graph_batch_ids, size=split_size, replace=False)
+        graph_split = train_triplets[graph_split_ids]
+        t = ns.transform(graph_batch)
+        return (graph_split, t[0], t[1])
+
+    return t_func
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Train a model on a given dataset.")
+    parser.add_argument("--settings", help="Filepath for settings file.", required=True)
+    parser.add_argument("--dataset", help="Filepath for dataset.", required=True)
+    parser.add_argument("--max-iterations", type=int, default=None,
+                        help="stop after this many iterations (sets Optimizer.MaxIterations)")
+    args = parser.parse_args(argv)
+
+    settings = settings_reader.read(args.settings)
+    print(settings)
+
+    encoder_settings = settings['Encoder']
+    decoder_settings = settings['Decoder']
+    shared_settings = settings['Shared']
+    general_settings = settings['General']
+    optimizer_settings = settings['Optimizer']
+    evaluation_settings = settings['Evaluation']
+
+    splits, entities, relations = load_dataset(args.dataset, evaluation_settings['Metric'])
+    train_triplets, valid_triplets, test_triplets = splits['train'], splits['valid'], splits['test']
+
+    general_settings.put('EntityCount', len(entities))
+    general_settings.put('RelationCount', len(relations))
+    general_settings.put('EdgeCount', len(train_triplets))
+    encoder_settings.merge(shared_settings)
+    encoder_settings.merge(general_settings)
+    decoder_settings.merge(shared_settings)
+    decoder_settings.merge(general_settings)
+    optimizer_settings.merge(general_settings)
+    evaluation_settings.merge(general_settings)
+    if args.max_iterations is not None:
+        optimizer_settings.put('MaxIterations', args.max_iterations)
+
+    encoder = model_builder.build_encoder(encoder_settings, train_triplets)
+    model = model_builder.build_decoder(encoder, decoder_settings)
+
+    opp = optimizer_parameter_parser.Parser(optimizer_settings)
+    opp.set_save_function(model.save)
+
+    scorer = evaluation.Scorer(evaluation_settings)
+    scorer.register_data(train_triplets)
+    scorer.register_data(valid_triplets)
+    scorer.register_data(test_triplets)
+    scorer.register_degrees(train_triplets)
+    scorer.register_model(model)
+    scorer.finalize_frequency_computation(np.concatenate((train_triplets, valid_triplets, test_triplets), axis=0))
+
+    def score_validation_data(validation_data):
+        score_summary = scorer.compute_scores(validation_data, verbose=False).get_summary()
+        early_stopping = score_summary.results['Filtered'][score_summary.mrr_string()]
+        score_summary = scorer.compute_scores(test_triplets, verbose=False).get_summary()
+        score_summary.pretty_print()
+        return early_stopping
+
+    opp.set_early_stopping_score_function(score_validation_data)
+    print(len(train_triplets))
+
+    if 'NegativeSampleRate' in general_settings:
+        opp.set_sample_transform_function(make_transform(train_triplets, general_settings, encoder))
+
+    model.preprocess(train_triplets)
+    model.register_for_test(train_triplets)
+    model.initialize_train()
+    print(model.get_train_input_variables())
+
+    optimizer = build_hip(model, opp.get_parametrization())
+    iterations = optimizer.fit(train_triplets, validation_data=valid_triplets)
+    return model, iterations
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,117 @@
+"""End to end through the reference-shaped driver (relationprediction_amd/train.py) on a small synthetic
+dataset written in the reference's file formats: the loss falls, validation MRR is computed on the device, the
+checkpoint is written in get_weights() order, and the chain's eager numpy surface agrees with the fused paths."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SETTINGS = """[Encoder]
+	Name=gcn_basis
+	DropoutKeepProbability=0.8
+	InternalEncoderDimension=20
+	NumberOfBasisFunctions=%(nb)d
+	NumberOfLayers=2
+	UseInputTransform=Yes
+	UseOutputTransform=No
+	AddDiagonal=No
+	DiagonalCoefficients=No
+	SkipConnections=None
+	StoreEdgeData=No
+	RandomInput=No
+	PartiallyRandomInput=No
+	Concatenation=%(concat)s
+
+[Decoder]
+	Name=bilinear-diag
+	RegularizationParameter=0.01
+
+[Shared]
+	CodeDimension=20
+
+[Optimizer]
+	MaxGradientNorm=1
+	ReportTrainLossEvery=10
+
+	[EarlyStopping]
+		CheckEvery=20
+		BurninPhaseDuration=1000
+
+	[Algorithm]
+		Name=Adam
+		learning_rate=0.01
+
+[General]
+	NegativeSampleRate=5
+	GraphSplitSize=0.5
+	ExperimentName=%(exp)s
+	GraphBatchSize=300
+
+[Evaluation]
+	Metric=MRR
+"""
+
+
+def write_dataset(root, V=200, R=6, n_train=700, seed=0):
+    """A learnable toy world: relation r maps entity e to (a_r * e + b_r) mod V."""
+    rng = np.random.RandomState(seed)
+    a, b = [1, 3, 7, 11, 13, 17][:R], rng.randint(0, V, R)
+    assert n_train + 120 <= V * R                 # the world only holds V*R distinct triples
+    triples = set()
+    while len(triples) < n_train + 120:
+        s, r = rng.randint(V), rng.randint(R)
+        triples.add((s, r, (a[r] * s + b[r]) % V))
+    triples = np.array(sorted(triples))
+    rng.shuffle(triples)
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "entities.dict"), "w") as f:
+        f.writelines("%d\te%d\n" % (i, i) for i in range(V))
+    with open(os.path.join(root, "relations.dict"), "w") as f:
+        f.writelines("%d\tr%d\n" % (i, i) for i in range(R))
+    for name, part in (("train", triples[:n_train]), ("valid", triples[n_train:n_train + 60]),
+                       ("test", triples[n_train + 60:n_train + 120])):
+        with open(os.path.join(root, name + ".txt"), "w") as f:
+            f.writelines("e%d\tr%d\te%d\n" % (s, r, o) for s, r, o in part)
+    return triples[:n_train]
+
+
+@pytest.mark.parametrize("concat,nb", [("Yes", 4), ("No", 2)])
+def test_train_driver_end_to_end(tmp_path, capsys, concat, nb):
+    from relationprediction_amd import train
+    data = str(tmp_path / "data")
+    train_triples = write_dataset(data)
+    os.makedirs(str(tmp_path / "models"))
+    exp = str(tmp_path / "models" / "Toy")
+    settings = tmp_path / "toy.exp"
+    settings.write_text(SETTINGS % dict(nb=nb, concat=concat, exp=exp))
+    np.random.seed(0)
+    model, iterations = train.main(["--settings", str(settings), "--dataset", data, "--max-iterations", "60"])
+    out = capsys.readouterr().out
+    assert iterations == 60
+    losses = [float(l.split(": ")[-1]) for l in out.splitlines() if l.startswith("Average train loss")]
+    initial = float([l for l in out.splitlines() if l.startswith("Initial loss")][0].split(": ")[1])
+    assert len(losses) == 5 and losses[-1] < 0.8 * initial, (initial, losses)
+    checks = [l for l in out.splitlines() if l.startswith("Tested validation score")]
+    assert len(checks) == 3 and all(0.0 < float(c.split("Result: ")[1]) <= 1.0 for c in checks)
+    assert "MRR" in out and "H@10" in out                            # test-set summary printed at every check
+    assert os.path.exists(exp + "-0.npz") and os.path.exists(exp + "-2.npz")
+    with np.load(exp + "-2.npz") as z:
+        names = sorted(z.files)
+        assert names[0].endswith("W_emb") and names[-1].endswith("W_relation")
+        assert z[names[-1]].shape == (200, 20)                        # [EntityCount, d]
+
+    # the eager numpy surface of the chain sees the weights the device optimizer trained
+    w = {v.name: v.value() for v in model.get_weights()}
+    assert np.isfinite(w["W_relation"]).all() and np.abs(w["W_relation"][:6]).mean() > 0.1
+    gvar, xvar = model.get_test_input_variables()
+    queries = train_triples[:7]
+    gvar.feed(train_triples)
+    xvar.feed(queries)
+    all_obj = model.predict_all_object_scores()                      # [7, V] sigmoid scores, host numpy
+    assert all_obj.shape == (7, 200)
+    ptr = np.arange(8, dtype=np.int64)
+    raw, filt = model.device_ranks(train_triples, queries, True, ptr, queries[:, 2].astype(np.int32))
+    host_raw = np.array([(row >= row[o]).sum() for row, o in zip(all_obj, queries[:, 2])])
+    assert np.abs(raw - host_raw).max() <= 1 and (filt == raw).all() # filter = gold only -> filtered == raw

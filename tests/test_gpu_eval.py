@@ -1,0 +1,91 @@
+"""Device ranking (include/rgcn.h rgcn_rank_device) against the oracle's restatement of the reference's
+MrrScore.append_line (code/common/evaluation.py:148-153) — `-m gpu`, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+def known_lists(triples, object_side):
+    known = {}
+    for s, r, o in triples:
+        key, val = ((s, r), o) if object_side else ((o, r), s)
+        lst = known.setdefault(key, [])
+        if val not in lst:                      # Scorer.extend_triple_dict keeps distinct values
+            lst.append(val)
+    return known
+
+
+def csr_for(queries, known, object_side):
+    ptr, idx = [0], []
+    for s, r, o in queries:
+        idx += known[(s, r) if object_side else (o, r)]
+        ptr.append(len(idx))
+    return np.asarray(ptr, np.int64), np.asarray(idx, np.int32)
+
+
+@pytest.mark.parametrize("V,R,d,nb,E,scale", [(120, 7, 20, 4, 500, 1.0), (300, 11, 40, 8, 1500, 1.0),
+                                              (90, 5, 20, 4, 400, 40.0)])
+def test_ranks_match_reference_definition(native, V, R, d, nb, E, scale):
+    """scale = 40 drives most energies into sigmoid saturation: scores tie at exactly 1.0 / 0.0 and the
+    `>=` comparison must count those ties as the reference does."""
+    params, triples, _, _ = make_case(V, R, d, 2, "block", nb, E, seed=E)
+    rng = np.random.RandomState(3)
+    params["W_relation"] = (rng.randn(V, d) * scale).astype(np.float32)
+    queries = triples[rng.choice(len(triples), 150, replace=False)].copy()
+    queries[:10] = queries[0]                                     # repeated queries
+    eng = native.Engine(V, R, d, 2, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        codes = eng.codes()
+        codes[5] = codes[6]                                       # (host copy only; ties come from saturation)
+        eng.rank_reserve(64)                                      # forces chunking: 150 queries, 64 per chunk
+        for object_side in (True, False):
+            known = known_lists(np.concatenate([triples, queries]), object_side)
+            ptr, idx = csr_for(queries, known, object_side)
+            raw, filt = eng.ranks(queries, object_side, ptr, idx)
+            oraw, ofilt = oracle.distmult_ranks(eng.codes(), params["W_relation"], queries, object_side, known)
+            assert (raw >= 1).all() and (filt >= 1).all() and (filt <= raw).all()
+            # energies come from two fp32 GEMMs with different summation orders: a near-tie may flip one rank
+            assert np.mean(raw != oraw) <= 0.02 and np.abs(raw - oraw).max() <= 1, (raw[:10], oraw[:10])
+            assert np.mean(filt != ofilt) <= 0.02 and np.abs(filt - ofilt).max() <= 1
+            if scale > 1:
+                assert (raw > 1).mean() > 0.3                     # saturation really produced ties
+    finally:
+        eng.close()
+
+
+def test_rank_argument_checks(native):
+    V, R, d = 50, 3, 8
+    params, triples, _, _ = make_case(V, R, d, 1, "block", 2, 60, seed=1)
+    eng = native.Engine(V, R, d, 1, "block", 2, max_edges=60)
+    try:
+        eng.set_params(params)
+        q = triples[:4]
+        ptr, idx = np.arange(5, dtype=np.int64), q[:, 2].astype(np.int32)
+        with pytest.raises(native.RgcnError):                     # no forward yet
+            eng.rank_reserve(8)
+            eng.ranks(q, True, ptr, idx)
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        bad = q.copy(); bad[1, 2] = V
+        with pytest.raises(native.RgcnError):
+            eng.ranks(bad, True, ptr, idx)
+        with pytest.raises(native.RgcnError):
+            eng.ranks(q, True, ptr, np.array([0, 1, V + 3, 2], np.int32))
+        raw, filt = eng.ranks(q, True, ptr, idx)                  # still usable afterwards
+        assert (filt >= 1).all()
+    finally:
+        eng.close()
