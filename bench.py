@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--workload", default="fb237_block", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="replay the steps from a captured hipGraph (two steps + their prefetches per launch; "
+                         "single GPU only)")
     ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("RGCN_GEMM_MODE", "6")), choices=[0, 6, 9],
                     help="arithmetic of the dense contractions (include/rgcn.h rgcn_set_gemm_mode): 6 / 9 = exact "
                          "bf16 operand split with 6 / 9 partial products on the bf16 matrix cores, 0 = fp32 MFMA")
@@ -146,6 +149,26 @@ def main():
 
     eng.set_gemm_mode(args.gemm_mode)
     run(args.warmup, 1000)
+    use_graph = args.hipgraph and world == 1 and pipeline
+    if use_graph:
+        if args.steps % 2:
+            sys.exit("--hipgraph: --steps must be even (one launch = two steps)")
+        # steady state of the pipelined loop as ONE graph: step on A beside the preparation of B, then the reverse
+        eng.prefetch_graph_device(graphs[0], E_g)
+        eng.sync()
+        eng.capture_begin()
+        for i in (0, 1):
+            eng.step_device(graphs[i], E_g, dc_dev, train=True, seed=2000 + i)
+            eng.prefetch_graph_device(graphs[1 - i], E_g)
+        graph_id = eng.capture_end()
+        plain_run = run
+
+        def run(n, seed0, pipeline=pipeline):   # noqa: F811  (timed loop: one launch per two steps)
+            if not pipeline:
+                return plain_run(n, seed0, pipeline=False)
+            for _ in range(n // 2):
+                eng.graph_launch(graph_id)
+        run(4, 0)
     barrier()
     t0 = time.perf_counter()
     eng.timer_start()
@@ -282,8 +305,9 @@ def main():
                     "reference-distribution random-init weights, synthetic upstream gradient",
             "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
-                       "step": "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
-                               "two alternating minibatches, next graph's prep pipelined on a side stream"
+                       "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
+                                "two alternating minibatches, next graph's prep pipelined on a side stream"
+                                + ("; replayed from a captured hipGraph (2 steps per launch)" if use_graph else ""))
                                if pipeline else
                                "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
                        "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},

@@ -227,6 +227,22 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, in
  * arrives through feed_dict at session.run (optimize.py:81-88). */
 rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev_next, int64_t num_edges);
 
+/* ---- hipGraph capture of whole steps (BASELINE config 5: "hipGraph-captured train step") -------------
+ * Between rgcn_capture_begin and rgcn_capture_end every asynchronous device call on the context
+ * (rgcn_step_device, rgcn_train_step_device, rgcn_prefetch_graph_device, rgcn_set_graph_device + rgcn_forward +
+ * rgcn_backward_device ...) is recorded into a hipGraph instead of being executed, side streams included;
+ * rgcn_graph_launch replays it on the context's stream with one launch.  Shapes and device pointers are the
+ * captured ones (static shapes: refresh the CONTENTS of the triple / batch buffers between launches); dropout
+ * masks differ from replay to replay (a device counter offsets the captured seeds) and Adam's step count
+ * advances on the device.  Calls that synchronise or touch host memory return RGCN_ERR_STATE during a capture;
+ * run one ordinary step first so that every lazily allocated buffer exists.  To keep the graph preparation of
+ * the next minibatch overlapped inside a graph, capture an even number of steps, each followed by the prefetch
+ * of the other triple buffer, with the first buffer prefetched (and finished) before the capture begins. */
+rgcn_status rgcn_capture_begin(rgcn_ctx* ctx);
+rgcn_status rgcn_capture_end(rgcn_ctx* ctx, int32_t* graph_id);
+rgcn_status rgcn_graph_launch(rgcn_ctx* ctx, int32_t graph_id);
+rgcn_status rgcn_graph_destroy(rgcn_ctx* ctx, int32_t graph_id);
+
 /* ---- relation sharding across GPUs (new: the reference is single-device) ------------
  * owner[r] in [0, world) assigns relation r's edges and W_f[r]/W_b[r] (BLOCK) or C_f[r]/C_b[r]
  * (BASIS) to one rank.  Degrees stay global.  Must be identical on all ranks. */

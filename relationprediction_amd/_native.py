@@ -72,6 +72,10 @@ _SIGS = {
     "rgcn_sampler_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "rgcn_sampler_destroy": (None, [_P]),
     "rgcn_sampler_edge_neighborhood": (C.c_int32, [_P, C.c_int64, C.c_uint64, _P]),
+    "rgcn_capture_begin": (C.c_int32, [_P]),
+    "rgcn_capture_end": (C.c_int32, [_P, C.POINTER(C.c_int32)]),
+    "rgcn_graph_launch": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_graph_destroy": (C.c_int32, [_P, C.c_int32]),
     "rgcn_rank_reserve": (C.c_int32, [_P, C.c_int64]),
     "rgcn_rank_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "rgcn_optimizer_step": (C.c_int32, [_P]),
@@ -291,6 +295,9 @@ class Engine:
     def get_grads(self):
         return {n: self.get_grad(n) for n in self.param_names}
 
+    def get_params(self):
+        return {n: self.get_param(n) for n in self.param_names}
+
     # -- graph
     def set_graph(self, triples):
         t = np.asarray(triples)
@@ -373,6 +380,21 @@ class Engine:
         v = C.c_double()
         self._check(self.lib.rgcn_get_loss(self.ctx, C.byref(v)))
         return float(v.value)
+
+    def capture_begin(self):
+        """Start recording device calls into a hipGraph (include/rgcn.h rgcn_capture_begin)."""
+        self._check(self.lib.rgcn_capture_begin(self.ctx))
+
+    def capture_end(self):
+        gid = C.c_int32(-1)
+        self._check(self.lib.rgcn_capture_end(self.ctx, C.byref(gid)))
+        return int(gid.value)
+
+    def graph_launch(self, graph_id):
+        self._check(self.lib.rgcn_graph_launch(self.ctx, int(graph_id)))
+
+    def graph_destroy(self, graph_id):
+        self._check(self.lib.rgcn_graph_destroy(self.ctx, int(graph_id)))
 
     def rank_reserve(self, max_queries):
         self._check(self.lib.rgcn_rank_reserve(self.ctx, int(max_queries)))

@@ -37,7 +37,8 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
 
 __device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
   if (ds.mode == DROP_NONE) return 1.0f;
-  if (ds.mode == DROP_RNG) return drop_bits(ds.seed, ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
+  if (ds.mode == DROP_RNG)
+    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
   return ds.mask[idx] ? ds.inv_keep : 0.0f;
 }
 

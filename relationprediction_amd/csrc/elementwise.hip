@@ -16,7 +16,8 @@ namespace {
 
 __device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
   if (ds.mode == DROP_NONE) return 1.0f;
-  if (ds.mode == DROP_RNG) return drop_bits(ds.seed, ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
+  if (ds.mode == DROP_RNG)
+    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
   return ds.mask[idx] ? ds.inv_keep : 0.0f;
 }
 
@@ -304,6 +305,7 @@ DropSpec make_drop(const rgcn_ctx* c, int layer, bool active) {
   ds.inv_keep = 1.0f / c->cfg.keep_prob;
   ds.seed = c->seed;
   ds.mask = nullptr;
+  ds.seed_offset = c->capturing ? c->replay_counter : nullptr;
   if (active && c->fwd_train && layer >= 1 && layer <= c->L) {
     if (c->explicit_masks) {
       ds.mode = DROP_MASK;

@@ -64,9 +64,11 @@ __global__ void __launch_bounds__(kOptThreads) k_sqnorm_part(OptTable tab, float
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// state[0] = clip scale, state[1] = global norm (for inspection)
+// state[0] = clip scale, state[1] = global norm (for inspection), state[2] = step count t, state[3] = the
+// bias-corrected rate lr * sqrt(1 - beta2^t) / (1 - beta1^t).  t advances HERE, on the device, so that a
+// captured hipGraph of the train step (rgcn_capture_*) keeps counting when it is replayed.
 __global__ void __launch_bounds__(256) k_clip_scale(const float* __restrict__ part, int nparts, float max_norm,
-                                                    float* __restrict__ state) {
+                                                    float lr, float b1, float b2, float* __restrict__ state) {
   __shared__ double red[256];
   double a = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
@@ -80,14 +82,17 @@ __global__ void __launch_bounds__(256) k_clip_scale(const float* __restrict__ pa
     const float norm = (float)sqrt(red[0]);
     state[1] = norm;
     state[0] = max_norm > 0.f ? max_norm / fmaxf(norm, max_norm) : 1.0f;
+    const double t = (double)state[2] + 1.0;
+    state[2] = (float)t;
+    state[3] = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
   }
 }
 
-__global__ void __launch_bounds__(kOptThreads) k_adam(OptTable tab, const float* __restrict__ state, float lr_t,
+__global__ void __launch_bounds__(kOptThreads) k_adam(OptTable tab, const float* __restrict__ state,
                                                       float b1, float b2, float eps) {
   const int ti = find_tensor(tab, blockIdx.x);
   const OptTensor t = tab.t[ti];
-  const float scale = state[0];
+  const float scale = state[0], lr_t = state[3];
   const int64_t base = (int64_t)(blockIdx.x - t.block0) * kOptThreads * kOptItems;
 #pragma unroll
   for (int k = 0; k < kOptItems; ++k) {
@@ -138,22 +143,22 @@ rgcn_status optimizer_step(rgcn_ctx* c) {
     o.part_cap = (size_t)nblocks;
   }
   if (!o.state) {
-    RGCN_HIP(c, hipMalloc((void**)&o.state, 2 * sizeof(float)));
+    RGCN_HIP(c, hipMalloc((void**)&o.state, 4 * sizeof(float)));
+    RGCN_HIP(c, hipMemsetAsync(o.state, 0, 4 * sizeof(float), c->stream));
   }
-  o.t += 1;
-  const double b1t = pow((double)o.beta1, (double)o.t), b2t = pow((double)o.beta2, (double)o.t);
-  const float lr_t = (float)((double)o.lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+  o.t += 1;        // host-side mirror (exact only while no captured graph is replayed)
   double total = 0;
   for (int i = 0; i < tab.count; ++i) total += (double)tab.t[i].n;
   {
     ProfScope ps(c, "opt_grad_norm", 4.0 * total, 2.0 * total);
     hipLaunchKernelGGL(k_sqnorm_part, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.part);
-    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nblocks, o.max_norm, o.state);
+    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nblocks, o.max_norm, o.lr, o.beta1,
+                       o.beta2, o.state);
   }
   {
     ProfScope ps(c, "opt_adam", 28.0 * total, 10.0 * total);
-    hipLaunchKernelGGL(k_adam, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.state, lr_t, o.beta1,
-                       o.beta2, o.eps);
+    hipLaunchKernelGGL(k_adam, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.state, o.beta1, o.beta2,
+                       o.eps);
   }
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;

@@ -59,6 +59,7 @@ rgcn_status stream_join(rgcn_ctx* c, int k) {
 }
 
 static rgcn_status sync_all(rgcn_ctx* c) {
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
   for (int k = 0; k < 2; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
@@ -130,6 +131,7 @@ static int auto_split_k(int M, int N, int K) {
 }
 
 static rgcn_status check_dev_flag(rgcn_ctx* c) {
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   int32_t flag = 0;
   if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
   for (int k = 0; k < 2; ++k)
@@ -145,11 +147,13 @@ static rgcn_status check_dev_flag(rgcn_ctx* c) {
 }
 
 static rgcn_status to_host(rgcn_ctx* c, void* host, const void* dev, size_t bytes) {
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
   RGCN_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   return RGCN_OK;
 }
 static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes) {
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
   RGCN_HIP(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));   // host memory is borrowed for the call only
   return RGCN_OK;
@@ -185,6 +189,10 @@ static void free_all(rgcn_ctx* c) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_step_begin) (void)hipEventDestroy(c->ev_step_begin);
+  for (hipGraphExec_t g : c->graphs) if (g) (void)hipGraphExecDestroy(g);
+  for (hipGraph_t g : c->graph_defs) if (g) (void)hipGraphDestroy(g);
+  if (c->replay_counter) (void)hipFree(c->replay_counter);
   if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
   if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
   delete c;
@@ -243,6 +251,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     }
   }
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, hipEventDisableTiming));
   {
     const char* e = getenv("RGCN_STREAMS");
     c->use_aux = !(e && atoi(e) == 0);
@@ -727,23 +736,36 @@ rgcn_status rgcn_backward(rgcn_ctx* c, const float* dcodes_host, int64_t count) 
   return backward_all(c, c->dcodes_own);
 }
 
-rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int32_t train,
-                             uint64_t seed, const float* dcodes_dev) {
-  RGCN_NEED(c);
-  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+// Start of a step: mark the point a prefetch may fork from, then adopt the prefetched structures of this
+// graph or build them in line.  While a hipGraph is being captured, events recorded BEFORE the capture began
+// must not be waited on (the replayed graph is ordered behind everything earlier on the stream anyway).
+static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
+  RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
+  c->step_begin_in_capture = c->capturing;
   if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E) {
     // the structures for this graph were prepared beside the previous step: swap them in
     std::swap(c->g, c->g_alt);
     c->g.pf_valid = false;
     c->fwd_done = false;
-    RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
-  } else {
-    RGCN_TRY(graph_build(c, tri_dev, E));
+    if (!c->capturing || c->g.ready_in_capture) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
+    return RGCN_OK;
   }
+  return graph_build(c, tri_dev, E);
+}
+static rgcn_status step_end(rgcn_ctx* c) {
+  RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
+  c->g.free_in_capture = c->capturing;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int32_t train,
+                             uint64_t seed, const float* dcodes_dev) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  RGCN_TRY(step_begin(c, tri_dev, E));
   RGCN_TRY(forward_all(c, train, seed, nullptr));
   RGCN_TRY(backward_all(c, dcodes_dev));
-  RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
-  return RGCN_OK;
+  return step_end(c);
 }
 
 // ---- decoder / optimizer / whole train step ("next" rows f1, f2) ---------------------------------
@@ -824,20 +846,13 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t 
     StreamScope side(c, 1);
     RGCN_TRY(decoder_prepare(c, X_dev, N));
   }
-  if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E) {
-    std::swap(c->g, c->g_alt);
-    c->g.pf_valid = false;
-    c->fwd_done = false;
-    RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
-  } else {
-    RGCN_TRY(graph_build(c, tri_dev, E));
-  }
+  RGCN_TRY(step_begin(c, tri_dev, E));
   RGCN_TRY(forward_all(c, 1, seed, nullptr));
   RGCN_TRY(stream_join(c, 1));
   RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
   c->dec.loss_valid = true;
   RGCN_TRY(backward_all(c, c->dcodes_own));
-  RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
+  RGCN_TRY(step_end(c));
   if (c->opt.configured) RGCN_TRY(optimizer_step(c));
   return RGCN_OK;
 }
@@ -851,7 +866,14 @@ rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int6
   std::swap(c->g, c->g_alt);
   rgcn_status s = RGCN_OK;
   do {
-    if (hipStreamWaitEvent(c->pf_stream, c->g.ev_free, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
+    if (c->capturing) {
+      // join the capture at the start of the step queued last (so that the preparation overlaps it), and
+      // behind the last captured step that used this buffer set
+      if (!c->step_begin_in_capture) { s = RGCN_ERR_STATE; c->err = "capture: queue a step before its prefetch"; break; }
+      if (hipStreamWaitEvent(c->pf_stream, c->ev_step_begin, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
+      if (c->g.free_in_capture && hipStreamWaitEvent(c->pf_stream, c->g.ev_free, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
+      c->cap_pf_forked = true;
+    } else if (hipStreamWaitEvent(c->pf_stream, c->g.ev_free, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
     c->stream = c->pf_stream;
     const bool was_done = c->fwd_done;
     s = graph_build(c, tri_dev, E);
@@ -859,6 +881,7 @@ rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int6
     c->stream = c->main_stream;
     if (s != RGCN_OK) break;
     if (hipEventRecord(c->g.ev_ready, c->pf_stream) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipEventRecord"; break; }
+    c->g.ready_in_capture = c->capturing;
     c->g.pf_tri = tri_dev;
     c->g.pf_E = E;
     c->g.pf_valid = true;
@@ -866,6 +889,94 @@ rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int6
   c->stream = c->main_stream;
   std::swap(c->g, c->g_alt);
   return s;
+}
+
+// ---- hipGraph capture of whole steps --------------------------------------------------------------
+namespace {
+__global__ void k_bump_counter(uint64_t* counter) { counter[0] += 1; }
+}
+
+rgcn_status rgcn_capture_begin(rgcn_ctx* c) {
+  RGCN_NEED(c);
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "a capture is already running");
+  if (c->prof_on) RGCN_FAIL(c, RGCN_ERR_STATE, "switch the per-kernel profile off before capturing");
+  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "capture on a sharded context (RCCL calls are not captured)");
+  RGCN_TRY(sync_all(c));
+  if (!c->replay_counter) {
+    RGCN_HIP(c, hipMalloc((void**)&c->replay_counter, sizeof(uint64_t)));
+    RGCN_HIP(c, hipMemset(c->replay_counter, 0, sizeof(uint64_t)));
+  }
+  c->g.ready_in_capture = c->g.free_in_capture = false;
+  c->g_alt.ready_in_capture = c->g_alt.free_in_capture = false;
+  c->step_begin_in_capture = false;
+  c->cap_pf_forked = false;
+  RGCN_HIP(c, hipStreamBeginCapture(c->main_stream, hipStreamCaptureModeRelaxed));
+  c->capturing = true;
+  hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, c->main_stream, c->replay_counter);
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_capture_end(rgcn_ctx* c, int32_t* graph_id) {
+  RGCN_NEED(c);
+  if (!c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "no capture is running");
+  if (!graph_id) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL graph_id");
+  hipError_t e = hipSuccess;
+  if (c->cap_pf_forked) {                      // the prefetch stream must rejoin the origin stream
+    e = hipEventRecord(c->ev_join[0], c->pf_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0);
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t e2 = hipStreamEndCapture(c->main_stream, &graph);
+  c->capturing = false;
+  // events last recorded inside the capture are unusable outside it: give them a fresh, ordinary record
+  (void)hipEventRecord(c->ev_fork, c->main_stream);
+  (void)hipEventRecord(c->ev_step_begin, c->main_stream);
+  for (int k = 0; k < 2; ++k) if (c->aux[k]) (void)hipEventRecord(c->ev_join[k], c->aux[k]);
+  for (rgcn::GraphBufs* g : {&c->g, &c->g_alt}) {
+    if (g->ev_ready) (void)hipEventRecord(g->ev_ready, c->pf_stream);
+    if (g->ev_free) (void)hipEventRecord(g->ev_free, c->main_stream);
+    g->ready_in_capture = g->free_in_capture = false;
+  }
+  if (c->dec.ev_ready) (void)hipEventRecord(c->dec.ev_ready, c->main_stream);
+  c->step_begin_in_capture = false;
+  if (e != hipSuccess || e2 != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    c->err = std::string("stream capture failed: ") + hipGetErrorString(e2 != hipSuccess ? e2 : e);
+    return RGCN_ERR_HIP;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return RGCN_ERR_HIP;
+  }
+  c->graph_defs.push_back(graph);
+  c->graphs.push_back(exec);
+  *graph_id = (int32_t)c->graphs.size() - 1;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_graph_launch(rgcn_ctx* c, int32_t graph_id) {
+  RGCN_NEED(c);
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "a capture is running");
+  if (graph_id < 0 || graph_id >= (int32_t)c->graphs.size() || !c->graphs[graph_id])
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown graph id");
+  RGCN_HIP(c, hipGraphLaunch(c->graphs[graph_id], c->main_stream));
+  c->fwd_done = true;       // the replayed steps leave activations / gradients of their last step behind
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_graph_destroy(rgcn_ctx* c, int32_t graph_id) {
+  RGCN_NEED(c);
+  if (graph_id < 0 || graph_id >= (int32_t)c->graphs.size() || !c->graphs[graph_id])
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown graph id");
+  RGCN_TRY(sync_all(c));
+  (void)hipGraphExecDestroy(c->graphs[graph_id]);
+  (void)hipGraphDestroy(c->graph_defs[graph_id]);
+  c->graphs[graph_id] = nullptr;
+  c->graph_defs[graph_id] = nullptr;
+  return RGCN_OK;
 }
 
 rgcn_status rgcn_set_relation_owner(rgcn_ctx* c, const int32_t* owner, int32_t count) {
@@ -949,6 +1060,7 @@ rgcn_status rgcn_device_alloc(rgcn_ctx* c, int64_t bytes, void** dev) {
 }
 rgcn_status rgcn_device_free(rgcn_ctx* c, void* dev) {
   RGCN_NEED(c);
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   if (dev) RGCN_HIP(c, hipFree(dev));
   return RGCN_OK;
@@ -966,11 +1078,13 @@ rgcn_status rgcn_copy_to_host(rgcn_ctx* c, void* host, const void* dev, int64_t 
 
 rgcn_status rgcn_timer_start(rgcn_ctx* c) {
   RGCN_NEED(c);
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "not allowed between rgcn_capture_begin and rgcn_capture_end");
   RGCN_HIP(c, hipEventRecord(c->t0, c->stream));
   return RGCN_OK;
 }
 rgcn_status rgcn_timer_stop(rgcn_ctx* c, float* ms) {
   RGCN_NEED(c);
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "not allowed between rgcn_capture_begin and rgcn_capture_end");
   if (!ms) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
   RGCN_HIP(c, hipEventRecord(c->t1, c->stream));
   RGCN_HIP(c, hipEventSynchronize(c->t1));

@@ -65,6 +65,7 @@ struct DropSpec {
   float inv_keep;       // 1 / keep_prob
   uint64_t seed;
   const uint8_t* mask;  // [V,d] 0/1 for this layer (DROP_MASK)
+  const uint64_t* seed_offset;  // device counter added to `seed` (replayed hipGraphs draw fresh masks); may be null
 };
 
 // ---------------------------------------------------------------- profiling records
@@ -145,6 +146,7 @@ struct GraphBufs {
   bool pf_valid = false;
   hipEvent_t ev_ready = nullptr;   // recorded on the prefetch stream when the set is complete
   hipEvent_t ev_free = nullptr;    // recorded on the main stream when the last step using the set ended
+  bool ready_in_capture = false, free_in_capture = false;   // those records belong to the running capture
   int32_t* owner = nullptr;     // [R]
   int32_t* errflag = nullptr;   // device int: nonzero = bad id seen
   bool ready = false;
@@ -234,6 +236,14 @@ struct rgcn_ctx {
   const float* bwd_D = nullptr;          // D_l of the backward layer in flight
   const float* bwd_dS = nullptr;         // dS_l = D_l * dropout_l
   int bwd_layer = 0;                     // next layer the backward pass will process (L..1, 0 = done)
+  // hipGraph capture (rgcn_capture_begin / _end / rgcn_graph_launch)
+  bool capturing = false;
+  bool cap_pf_forked = false;            // the prefetch stream has joined the capture and must be joined back
+  uint64_t* replay_counter = nullptr;    // device counter bumped at the start of every captured graph
+  hipEvent_t ev_step_begin = nullptr;    // recorded on the main stream where a step starts (capture: fork point of the prefetch)
+  bool step_begin_in_capture = false;
+  std::vector<hipGraphExec_t> graphs;
+  std::vector<hipGraph_t> graph_defs;
   float *rank_q = nullptr, *rank_s = nullptr;   // ranking: query rows [max,d], energies [max,V]
   int32_t* rank_bad = nullptr;
   int64_t rank_max = 0;

@@ -1,0 +1,103 @@
+"""hipGraph capture of whole steps (include/rgcn.h rgcn_capture_*): a replayed graph must do exactly what the
+same calls do when issued one by one — bitwise, dropout and Adam's step count included."""
+import numpy as np
+import pytest
+
+from helpers import make_case
+from test_gpu_train_step import decoder_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+def make_engine(native, kind="block", nb=4, V=80, R=6, d=20, E=300, seed=4):
+    params, triples, masks, dcodes = make_case(V, R, d, 2, kind, nb, E, seed=seed)
+    eng = native.Engine(V, R, d, 2, kind, nb, max_edges=E)
+    eng.set_params(params)
+    return eng, params, triples, dcodes
+
+
+@pytest.mark.parametrize("kind,nb", [("block", 4), ("basis", 2)])
+def test_captured_encoder_steps_replay_bitwise(native, kind, nb):
+    eng, params, triples, dcodes = make_engine(native, kind, nb)
+    ref, _, _, _ = make_engine(native, kind, nb)
+    try:
+        rng = np.random.RandomState(0)
+        ta, tb = triples, triples[rng.permutation(len(triples))[:250]]
+        bufs = {}
+        for e, tag in ((eng, "c"), (ref, "r")):
+            bufs[tag] = (e.to_device(ta), e.to_device(tb), e.to_device(dcodes))
+        A, B, D = bufs["c"]
+        eng.step_device(A, len(ta), D, train=True, seed=1)              # ordinary step: lazy allocations happen here
+        eng.prefetch_graph_device(A, len(ta))
+        eng.sync()
+        eng.capture_begin()
+        eng.step_device(A, len(ta), D, train=True, seed=100)
+        eng.prefetch_graph_device(B, len(tb))
+        eng.step_device(B, len(tb), D, train=True, seed=200)
+        eng.prefetch_graph_device(A, len(ta))
+        with pytest.raises(native.RgcnError):
+            eng.get_grads()                                             # host transfer inside a capture
+        gid = eng.capture_end()
+        rA, rB, rD = bufs["r"]
+        for launch in (1, 2, 3):
+            eng.graph_launch(gid)
+            grads = eng.get_grads()
+            # the same two steps one by one; replay k draws dropout from (captured seed + k)
+            ref.step_device(rA, len(ta), rD, train=True, seed=100 + launch)
+            ref.step_device(rB, len(tb), rD, train=True, seed=200 + launch)
+            want = ref.get_grads()
+            for k in want:
+                if want[k] is not None:
+                    assert np.array_equal(grads[k], want[k]), (launch, k)
+        # the context is still usable the ordinary way, and graphs can be dropped
+        eng.step_device(A, len(ta), D, train=True, seed=7)
+        ref.step_device(rA, len(ta), rD, train=True, seed=7)
+        assert all(np.array_equal(eng.get_grads()[k], ref.get_grads()[k]) for k in ("W_emb", "W_self1"))
+        eng.graph_destroy(gid)
+        with pytest.raises(native.RgcnError):
+            eng.graph_launch(gid)
+    finally:
+        for t in bufs.values():
+            for b in t:
+                b.free()
+        eng.close()
+        ref.close()
+
+
+def test_captured_train_step_matches_stepwise_training(native):
+    eng, params, triples, _ = make_engine(native)
+    ref, _, _, _ = make_engine(native)
+    try:
+        X, Y = decoder_batch(np.random.RandomState(1), triples, 80)
+        held = []
+        for e in (eng, ref):
+            e.decoder_reserve(len(X))
+            e.optimizer_config(lr=0.01, max_grad_norm=1.0)
+            held.append((e.to_device(triples), e.to_device(X), e.to_device(Y)))
+        (T, Xd, Yd), (rT, rX, rY) = held
+        eng.train_step_device(T, len(triples), Xd, Yd, len(X), seed=5, reg_param=0.01)   # warm-up, also on ref
+        ref.train_step_device(rT, len(triples), rX, rY, len(X), seed=5, reg_param=0.01)
+        eng.sync()
+        eng.capture_begin()
+        eng.train_step_device(T, len(triples), Xd, Yd, len(X), seed=50, reg_param=0.01)
+        gid = eng.capture_end()
+        for launch in (1, 2, 3, 4):
+            eng.graph_launch(gid)
+            ref.train_step_device(rT, len(triples), rX, rY, len(X), seed=50 + launch, reg_param=0.01)
+            assert eng.loss() == ref.loss(), launch
+        got, want = eng.get_params(), ref.get_params()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k                    # Adam's t advanced on the device
+    finally:
+        for t in held:
+            for b in t:
+                b.free()
+        eng.close()
+        ref.close()
