@@ -390,13 +390,26 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
   if (c->kind == RGCN_KIND_BLOCK) {
-    {   // the relational messages (HBM-bound) run beside the self-loop GEMM (MFMA-bound)
-      StreamScope side(c, 0);
+    // The relational messages (HBM-bound) run beside the self-loop GEMM.  A stream that blocks on another
+    // stream's event resumes ~10 us after the event fires, so the chain that continues (the combine) stays on
+    // the stream of the kernel that finishes LAST: schedule 1 keeps the messages on the main stream and
+    // forks the (shorter) GEMM; schedule 0 is the reverse.
+    static const int fsched = getenv("RGCN_FWD_SCHED") ? atoi(getenv("RGCN_FWD_SCHED")) : 1;
+    if (fsched == 1) {
+      {   // self-loop: S = H . W_self  (rows of this rank's shard)
+        StreamScope side(c, 0);
+        RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                          c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+      }
       RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    } else {
+      {
+        StreamScope side(c, 0);
+        RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+      }
+      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     }
-    // self-loop: S = H . W_self  (rows of this rank's shard)
-    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                      c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     RGCN_TRY(stream_join(c, 0));
     CombineArgs a;
     a.add = nullptr;
