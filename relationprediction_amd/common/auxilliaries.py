@@ -18,15 +18,17 @@ class NegativeSampler(object):
         self.negative_sample_rate = int(negative_sample_rate)
         self.n_entities = int(n_entities)
 
-    def transform(self, triplets):
+    def transform(self, triplets, rng=None):
+        """`rng`: a numpy RandomState to draw from instead of the global one (background batch producers)."""
+        rng = np.random if rng is None else rng
         triplets = np.asarray(triplets)
         size_of_batch = len(triplets)
         number_to_generate = size_of_batch * self.negative_sample_rate
         new_labels = np.zeros(size_of_batch * (self.negative_sample_rate + 1), dtype=np.float32)
         new_indexes = np.tile(triplets, (self.negative_sample_rate + 1, 1)).astype(np.int32)
         new_labels[:size_of_batch] = 1
-        choices = np.random.binomial(1, 0.5, number_to_generate).astype(bool)
-        values = np.random.randint(self.n_entities, size=number_to_generate)
+        choices = rng.binomial(1, 0.5, number_to_generate).astype(bool)
+        values = rng.randint(self.n_entities, size=number_to_generate)
         negatives = new_indexes[size_of_batch:]
         negatives[choices, 2] = values[choices]
         negatives[~choices, 0] = values[~choices]

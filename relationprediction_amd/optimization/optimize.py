@@ -112,6 +112,16 @@ class SampleTransformer(IOptimizer):           # shared/algorithms.py:51-60
     def process_data(self, training_data):
         return self.transform_function(self.next_component.process_data(training_data))
 
+    def deferred(self, training_data):
+        """(callable, seed) building the same batch later, possibly on another thread — available when the
+        transform function is a pure function of (data, seed) (`transform_function.seeded`)."""
+        seeded = getattr(self.transform_function, 'seeded', None)
+        if seeded is None or not isinstance(self.next_component, BaseOptimizer):
+            return None
+        seed = int(np.random.randint(0, 2 ** 31 - 1))       # drawn in request order: reproducible
+        data = self.next_component.process_data(training_data)
+        return lambda: seeded(data, seed)
+
 
 class GradientClipping(IOptimizer):            # tensorflow_backend/algorithms.py:58-68 (clip_by_global_norm)
     max_norm = None
@@ -232,9 +242,10 @@ def build_stack(parameters):
 class HipOptimizer(object):
     """TensorflowOptimizer's role (optimize.py:42-90) on the device train step."""
 
-    def __init__(self, stack, model):
+    def __init__(self, stack, model, batch_workers=0):
         self.stack = stack
         self.model = model
+        self.batch_workers = int(batch_workers)
         cfg = {}
         stack.configure_device(cfg)
         if 'learning_rate' not in cfg:
@@ -247,26 +258,73 @@ class HipOptimizer(object):
         graph_edges, x, y = processed_batch
         self.model.device_train_step(graph_edges, x, y, seed)
 
+    def _sample_transformer(self):
+        """The SampleTransformer if it sits directly on the data source (the only place the reference puts it
+        when no Minibatches component is configured)."""
+        comp = self.stack
+        while comp is not None:
+            if isinstance(comp, SampleTransformer):
+                return comp
+            comp = comp.next_component
+        return None
+
+    def _batches(self):
+        """Generator of processed batches in request order.  With batch_workers > 0 and a seedable transform the
+        batches are built by a thread pool up to batch_workers + 1 ahead of the consumer (the neighbourhood
+        sampler and most numpy work release the GIL); otherwise each batch is built when asked for."""
+        st = self._sample_transformer()
+        pool = None
+        if self.batch_workers > 0 and st is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=self.batch_workers)
+        try:
+            pending = []
+            exhausted = False
+
+            def request():
+                nonlocal exhausted
+                if exhausted:
+                    return
+                nb = self.stack.next_batch()
+                if nb is None:
+                    exhausted = True
+                    return
+                job = st.deferred(nb) if pool is not None else None
+                pending.append(pool.submit(job) if job is not None else ('inline', nb))
+            depth = self.batch_workers + 1 if pool is not None else 1
+            for _ in range(depth):
+                request()
+            while pending:
+                head = pending.pop(0)
+                if isinstance(head, tuple):
+                    yield self.stack.process_data(head[1])
+                else:
+                    yield head.result()
+                request()
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=False)
+
     def fit(self, training_data, validation_data=None):
         self.stack.set_training_data(training_data)
         if validation_data is not None:
             self.stack.set_validation_data(validation_data)
         i = 0
-        next_batch = self.stack.next_batch()
-        processed = self.stack.process_data(next_batch) if next_batch is not None else None
+        batches = self._batches()
+        processed = next(batches, None)
         while processed is not None:
             i += 1
             self.stack.set_iteration(i)
             self.update_from_batch(processed, seed=int(np.random.randint(0, 2 ** 31 - 1)))
-            # host work of the next iteration while the device runs this one
-            next_batch = self.stack.next_batch()
-            processed = self.stack.process_data(next_batch) if next_batch is not None else None
+            # host work of the next iteration (or the wait for a background-built batch) while the device runs
+            processed = next(batches, None)
             train_loss = self.model.device_loss()            # synchronises with the step
             if self.stack.postprocess(train_loss) == 'stop':
                 print("Stopping training.")
                 break
+        batches.close()
         return i
 
 
-def build_hip(model, parameters):
-    return HipOptimizer(build_stack(parameters), model)
+def build_hip(model, parameters, batch_workers=0):
+    return HipOptimizer(build_stack(parameters), model, batch_workers=batch_workers)

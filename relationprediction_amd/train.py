@@ -29,31 +29,42 @@ def load_dataset(dataset, metric='MRR'):
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
 
-def make_transform(train_triplets, general_settings, encoder, seed_source=np.random):
-    """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y)."""
+def make_transform(train_triplets, general_settings, encoder):
+    """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y).
+
+    Every batch is a function of ONE seed drawn from numpy's global generator when the batch is requested, so
+    batches can be built ahead of time by background threads (`t_func.seeded(data, seed)`, used by
+    optimization.optimize.HipOptimizer) and still come out in a reproducible order; `t_func(data)` itself
+    draws the seed and builds the batch in place, like the reference's function."""
+    import threading
     ns = auxilliaries.NegativeSampler(int(general_settings['NegativeSampleRate']), general_settings['EntityCount'])
     ns.set_known_positives(train_triplets)
-    sampler = None
-    if 'GraphBatchSize' in general_settings:
-        sampler = _native.NeighborhoodSampler(train_triplets, int(general_settings['EntityCount']))
+    use_sampler = 'GraphBatchSize' in general_settings
+    local = threading.local()            # the native sampler keeps per-sample state: one per thread
 
-    def t_func(x):
-        arr = np.array(x)
+    def seeded(x, seed):
+        rng = np.random.RandomState(seed)
+        arr = np.asarray(x)
         if not encoder.needs_graph():
-            return ns.transform(arr)
-        if sampler is not None:
-            graph_batch_size = int(general_settings['GraphBatchSize'])
-            graph_batch_ids = sampler.sample(graph_batch_size, seed_source.randint(0, 2 ** 31 - 1))
+            return ns.transform(arr, rng)
+        if use_sampler:
+            if not hasattr(local, 'sampler'):
+                local.sampler = _native.NeighborhoodSampler(train_triplets, int(general_settings['EntityCount']))
+            graph_batch_ids = local.sampler.sample(int(general_settings['GraphBatchSize']), rng.randint(0, 2 ** 31 - 1))
         else:
             graph_batch_ids = np.arange(arr.shape[0])
         graph_batch = train_triplets[graph_batch_ids]
         # edge dropout: the encoder sees a random GraphSplitSize fraction of the batch (exact-k, host side, :235-238)
         split_size = int(float(general_settings['GraphSplitSize']) * graph_batch.shape[0])
-        graph_split_ids = np.random.choice(graph_batch_ids, size=split_size, replace=False)
+        graph_split_ids = rng.choice(graph_batch_ids, size=split_size, replace=False)
         graph_split = train_triplets[graph_split_ids]
-        t = ns.transform(graph_batch)
+        t = ns.transform(graph_batch, rng)
         return (graph_split, t[0], t[1])
 
+    def t_func(x):
+        return seeded(x, np.random.randint(0, 2 ** 31 - 1))
+
+    t_func.seeded = seeded
     return t_func
 
 
@@ -63,6 +74,8 @@ def main(argv=None):
     parser.add_argument("--dataset", help="Filepath for dataset.", required=True)
     parser.add_argument("--max-iterations", type=int, default=None,
                         help="stop after this many iterations (sets Optimizer.MaxIterations)")
+    parser.add_argument("--batch-workers", type=int, default=8,
+                        help="background threads that build minibatches ahead of the device (0: build in line)")
     args = parser.parse_args(argv)
 
     settings = settings_reader.read(args.settings)
@@ -122,7 +135,7 @@ def main(argv=None):
     model.initialize_train()
     print(model.get_train_input_variables())
 
-    optimizer = build_hip(model, opp.get_parametrization())
+    optimizer = build_hip(model, opp.get_parametrization(), batch_workers=args.batch_workers)
     iterations = optimizer.fit(train_triplets, validation_data=valid_triplets)
     return model, iterations
 

@@ -227,3 +227,35 @@ def test_iteration_counter_and_unknown_component(tmp_path):
     assert optimize.build_hip(model, opp.get_parametrization()).fit([0]) == 5
     with pytest.raises(NotImplementedError):
         optimize.build_stack([('RmsProp', {'learning_rate': 0.1})])
+
+
+def test_background_batch_producers_are_reproducible(tmp_path):
+    """Batches built ahead by worker threads come out in request order and depend only on the seeds drawn in
+    that order: two runs from the same numpy seed see the same batches; a graph-free encoder stub keeps it CPU-only."""
+    from relationprediction_amd import train
+
+    class NoGraphEncoder(object):
+        def needs_graph(self):
+            return False
+
+    rng = np.random.RandomState(0)
+    triples = np.stack([rng.randint(0, 30, 200), rng.randint(0, 3, 200), rng.randint(0, 30, 200)], 1).astype(np.int32)
+    general = {'NegativeSampleRate': '2', 'EntityCount': 30}
+    runs = []
+    for workers in (3, 3, 0, 0):
+        opp = optimizer_parameter_parser.Parser(reference_settings(tmp_path, extra="\tMaxIterations=12"))
+        model = FakeTrainModel(losses=[1.0] * 40)
+        opp.set_early_stopping_score_function(lambda data: 1.0)
+        opp.set_save_function(model.save)
+        t_func = train.make_transform(triples, general, NoGraphEncoder())
+        opp.set_sample_transform_function(lambda x, f=t_func: (None,) + tuple(f(x)))
+        wrapped = opp.sample_transform_function
+        wrapped.seeded = lambda x, seed, f=t_func: (None,) + tuple(f.seeded(x, seed))
+        np.random.seed(5)
+        assert optimize.build_hip(model, opp.get_parametrization(), batch_workers=workers).fit(triples) == 12
+        runs.append([(s[1].copy(), s[2].copy()) for s in model.steps])
+    for a, b in ((runs[0], runs[1]), (runs[2], runs[3])):
+        assert all((x[0] == y[0]).all() and (x[1] == y[1]).all() for x, y in zip(a, b))
+    first = runs[0]
+    assert first[0][0].shape == (600, 3) and (first[0][1][:200] == 1).all()
+    assert any((first[0][0] != first[k][0]).any() for k in range(1, 12))      # batches differ from one another

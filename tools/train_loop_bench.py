@@ -56,7 +56,7 @@ def main():
     triples = oracle.synthetic_graph(V, R, E, np.random.RandomState(0)).astype(np.int32)
     path = "/tmp/rgcn_train_loop_bench.exp"
     with open(path, "w") as f:
-        f.write(SETTINGS % (2 * iters + 5))
+        f.write(SETTINGS % (iters + 5))
     s = settings_reader.read(path)
     general = s['General']
     general.put('EntityCount', V); general.put('RelationCount', R); general.put('EdgeCount', E)
@@ -97,10 +97,28 @@ def main():
     wall = time.perf_counter() - t0
     print("serial loop: %.2f ms / iteration  (host minibatch construction %.2f ms, device step %.3f ms, loss %.4f)"
           % (wall * 1e3 / iters, np.mean(host_times[5:]) * 1e3, np.mean(dev_ms), loss))
-    t0 = time.perf_counter()
-    n = opt.fit(triples)
-    print("driver loop (next batch drawn while the device runs): %.2f ms / iteration over %d iterations"
-          % ((time.perf_counter() - t0) * 1e3 / n, n))
+    # per-kernel durations of the device step (side-stream overlap off: exclusive times)
+    eng.set_overlap(False)
+    eng.profile_reset(); eng.profile_enable(True)
+    for i in range(10):
+        opt.update_from_batch(batch, seed=100 + i)
+    eng.sync()
+    prof = sorted(eng.profile(), key=lambda p: -p["total_ms"])
+    eng.profile_enable(False); eng.set_overlap(True)
+    tot = sum(p["total_ms"] for p in prof) / 10
+    print("device step kernels (exclusive, ms per step, total %.3f):" % tot)
+    for p_ in prof[:14]:
+        print("   %-24s %5.1f launches  %.4f ms" % (p_["name"], p_["calls"] / 10, p_["total_ms"] / 10))
+    for workers in (0, 8):
+        opp2 = optimizer_parameter_parser.Parser(s['Optimizer'])
+        opp2.set_save_function(lambda p: None)
+        opp2.set_sample_transform_function(t_func)
+        opt2 = build_hip(model, [p for p in opp2.get_parametrization() if p[0] != 'ModelSaver'], batch_workers=workers)
+        opt2.stack.next_component  # noqa: B018
+        t0 = time.perf_counter()
+        n = opt2.fit(triples)
+        print("driver loop, %d background batch builders: %.2f ms / iteration over %d iterations"
+              % (workers, (time.perf_counter() - t0) * 1e3 / n, n))
 
 
 if __name__ == "__main__":
