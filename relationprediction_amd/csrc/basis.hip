@@ -449,12 +449,12 @@ rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const
 rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* dZ) {
   const int R2 = 2 * c->R;
   if (c->g.E > 0) {
-    const int nchunks = (int)((2 * c->g.E + c->chunk - 1) / c->chunk) + R2;
+    const int nchunks = (int)((2 * c->g.E + c->g.chunk - 1) / c->g.chunk) + R2;
     if ((size_t)nchunks * c->B > c->slab_dw_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: dC slab too small");
     DcoefArgs a;
     a.Hin = Hin; a.dZ = dZ; a.m_src = c->g.m_src; a.m_dst = c->g.m_dst; a.m_norm = c->g.m_norm;
     a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr; a.slab = c->slab_dw;
-    a.R = c->R; a.B = c->B; a.d = c->d; a.chunk = c->chunk;
+    a.R = c->R; a.B = c->B; a.d = c->d; a.chunk = c->g.chunk;
     const double M = 2.0 * c->g.E / c->world;
     ProfScope ps(c, "basis_dcoef", 4.0 * c->d * M * (1.0 + c->B), 2.0 * M * c->B * c->d);
     if (c->d % 4 == 0 && aligned16(Hin) && aligned16(dZ))

@@ -179,7 +179,7 @@ __global__ void k_block_transpose(const float* __restrict__ in, float* __restric
 
 int max_chunks(const rgcn_ctx* c) {
   const int64_t M = 2 * c->g.E;
-  return (int)((M + c->chunk - 1) / c->chunk) + 2 * c->R;
+  return (int)((M + c->g.chunk - 1) / c->g.chunk) + 2 * c->R;
 }
 
 template <typename F>
@@ -226,7 +226,7 @@ rgcn_status block_msg_forward(rgcn_ctx* c, int layer, const float* Hin, float* Y
   a.Hin = Hin; a.D = nullptr; a.W = c->layers[layer].wrel; a.out = Ybuf; a.slab = nullptr;
   a.m_src = c->g.m_src; a.m_dst = c->g.m_dst; a.m_slot = c->g.m_dslot; a.m_norm = c->g.m_norm;
   a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr;
-  a.R2 = 2 * c->R; a.nb = c->nb; a.d = c->d; a.chunk = c->chunk; a.G = c->msg_slots;
+  a.R2 = 2 * c->R; a.nb = c->nb; a.d = c->d; a.chunk = c->g.chunk; a.G = c->msg_slots;
   const double M = 2.0 * c->g.E / c->world;
   ProfScope ps(c, "block_msg_fwd", M * (8.0 * c->d + 16.0) + 8.0 * c->R * c->nb * c->sd * c->sd,
                M * 2.0 * c->d * c->sd);
@@ -249,7 +249,7 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
     a.Hin = Hin; a.D = D; a.W = c->layers[layer].wrel; a.out = Zbuf; a.slab = c->slab_dw;
     a.m_src = c->g.m_src; a.m_dst = c->g.m_dst; a.m_slot = c->g.m_sslot; a.m_norm = c->g.m_norm;
     a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr;
-    a.R2 = R2; a.nb = c->nb; a.d = c->d; a.chunk = c->chunk; a.G = c->msg_slots;
+    a.R2 = R2; a.nb = c->nb; a.d = c->d; a.chunk = c->g.chunk; a.G = c->msg_slots;
     const size_t lds = (size_t)(c->msg_slots - 1) * per_rel * sizeof(float);
     const double M = 2.0 * c->g.E / c->world;
     ProfScope ps(c, "block_msg_bwd", M * (12.0 * c->d + 20.0) + 16.0 * c->R * per_rel,

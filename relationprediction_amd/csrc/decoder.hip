@@ -23,7 +23,9 @@ namespace rgcn {
 
 namespace {
 
-constexpr int kDecLongRow = 256;    // entity rows with more incidences get a whole workgroup
+constexpr int kDecLongRow = 256;    // entity rows with more incidences are cut into pieces, one workgroup each
+constexpr int kDecPiece = 512;      // incidences per piece: a hub entity (tens of thousands of incidences in a
+                                    // neighbourhood-sampled batch with its tiled negatives) spreads over many CUs
 constexpr int kDecChunk = 128;      // triples per relation chunk
 constexpr int kRowThreads = 1024;
 
@@ -73,7 +75,9 @@ __global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, u
 __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ keyv_s,
                                                    const uint32_t* __restrict__ keyr_s, int N, int V, int R,
                                                    int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
-                                                   int32_t* rel_ptr, int32_t* chunk_ptr) {
+                                                   int32_t* long_first, int32_t* long_cnt, int32_t* piece_row,
+                                                   int32_t* piece_k, int piece_cap, int32_t* rel_ptr,
+                                                   int32_t* chunk_ptr) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -116,8 +120,14 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, 2 * N, (uint32_t)(v + 1));
   if (end - beg > kDecLongRow) {
+    // pieces of one row get consecutive ids, so the finishing pass adds them in a fixed order whatever
+    // order the rows were registered in
+    const int np = (end - beg + kDecPiece - 1) / kDecPiece;
     const int i = atomicAdd(nlong, 1);
-    if (i < cap) long_rows[i] = v;
+    const int base = atomicAdd(nlong + 1, np);
+    if (i < cap) { long_rows[i] = v; long_first[i] = base; long_cnt[i] = np; }
+    for (int k = 0; k < np; ++k)
+      if (base + k < piece_cap) { piece_row[base + k] = v; piece_k[base + k] = k; }
   }
 }
 
@@ -217,6 +227,11 @@ struct EntArgs {
   const int32_t* e_trip;
   const int32_t* long_rows;
   const int32_t* nlong;
+  const int32_t* long_first;
+  const int32_t* long_cnt;
+  const int32_t* piece_row;
+  const int32_t* piece_k;
+  float* piece_slab;
   float* dcodes;
   int32_t V, d;
   float k;                  // 2 lambda / (N d)
@@ -258,10 +273,12 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int 
   if ((int)blockIdx.x < n_long_blocks) {
     __shared__ float red[8][128 * VEC];
     const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    const int n = *a.nlong;
+    // one PIECE of a long row per turn: 8 slot lanes x 128 column lanes, partial sum to the piece slab
+    const int n = a.nlong[1];
     for (int lb = blockIdx.x; lb < n; lb += n_long_blocks) {
-      const int v = a.long_rows[lb];
-      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      const int v = a.piece_row[lb];
+      const int beg = a.row_ptr[v] + a.piece_k[lb] * kDecPiece;
+      const int end = min(a.row_ptr[v + 1], beg + kDecPiece);
       for (int c0 = 0; c0 < nvec; c0 += 128) {
         const int cidx = c0 + cl;
         float acc[VEC];
@@ -272,18 +289,14 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int 
         for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
         __syncthreads();
         if (sl == 0 && cidx < nvec) {
-          const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
-          float self[VEC];
-          vload<VEC>(a.codes + off, self);
-          const float kc = a.k * (float)(end - beg);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
             float t = red[0][cl * VEC + k];
 #pragma unroll
             for (int w = 1; w < 8; ++w) t += red[w][cl * VEC + k];
-            acc[k] = fmaf(kc, self[k], t);
+            acc[k] = t;
           }
-          vstore<VEC>(a.dcodes + off, acc);
+          vstore<VEC>(a.piece_slab + (size_t)lb * a.d + (size_t)cidx * VEC, acc);
         }
         __syncthreads();
       }
@@ -306,6 +319,32 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int 
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = fmaf(kc, self[k], acc[k]);
     vstore<VEC>(a.dcodes + off, acc);
+  }
+}
+
+// long rows: add the pieces of every row in piece order, plus the regulariser's share of the row itself
+template <int VEC>
+__global__ void __launch_bounds__(256) k_dec_long_finish(EntArgs a) {
+  const int nvec = a.d / VEC;
+  const int n = a.nlong[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int v = a.long_rows[i], first = a.long_first[i], cnt = a.long_cnt[i];
+    const float kc = a.k * (float)(a.row_ptr[v + 1] - a.row_ptr[v]);
+    for (int cidx = threadIdx.x; cidx < nvec; cidx += 256) {
+      const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+      float acc[VEC], self[VEC], part[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+      for (int p = 0; p < cnt; ++p) {
+        vload<VEC>(a.piece_slab + (size_t)(first + p) * a.d + (size_t)cidx * VEC, part);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += part[k];
+      }
+      vload<VEC>(a.codes + off, self);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(kc, self[k], acc[k]);
+      vstore<VEC>(a.dcodes + off, acc);
+    }
   }
 }
 
@@ -428,7 +467,13 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.e_other, 2 * N)); RGCN_TRY(dalloc(c, &q.e_rel, 2 * N)); RGCN_TRY(dalloc(c, &q.e_trip, 2 * N));
   q.long_cap = (int32_t)(2 * N / kDecLongRow + 1);
   RGCN_TRY(dalloc(c, &q.long_rows, (size_t)q.long_cap));
-  RGCN_TRY(dalloc(c, &q.nlong, 1));
+  RGCN_TRY(dalloc(c, &q.long_first, (size_t)q.long_cap));
+  RGCN_TRY(dalloc(c, &q.long_cnt, (size_t)q.long_cap));
+  q.piece_cap = (int32_t)(2 * N / kDecPiece + q.long_cap + 1);     // sum of ceil(len / piece) over the long rows
+  RGCN_TRY(dalloc(c, &q.piece_row, (size_t)q.piece_cap));
+  RGCN_TRY(dalloc(c, &q.piece_k, (size_t)q.piece_cap));
+  RGCN_TRY(dalloc(c, &q.piece_slab, (size_t)q.piece_cap * d));
+  RGCN_TRY(dalloc(c, &q.nlong, 2));
   RGCN_TRY(dalloc(c, &q.dx, N));
   q.energy_blocks = 2048;
   RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)q.energy_blocks));
@@ -454,7 +499,7 @@ void decoder_free(rgcn_ctx* c) {
   DecoderBufs& q = c->dec;
   void* ptrs[] = {q.keyv, q.keyv_s, q.valv, q.permv, q.keyr, q.keyr_s, q.valr, q.permr, q.row_ptr, q.rel_ptr,
                   q.chunk_ptr, q.e_other, q.e_rel, q.e_trip, q.long_rows, q.nlong, q.dx, q.loss_part, q.loss,
-                  q.slab, q.sort_tmp};
+                  q.slab, q.sort_tmp, q.long_first, q.long_cnt, q.piece_row, q.piece_k, q.piece_slab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (q.ev_ready) (void)hipEventDestroy(q.ev_ready);
@@ -468,7 +513,7 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
   if (N64 > q.maxN) RGCN_FAIL(c, RGCN_ERR_INVALID, "decoder batch larger than rgcn_decoder_reserve'd");
   q.N = N;
   q.X = X;
-  RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, sizeof(int32_t), c->stream));
+  RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, 2 * sizeof(int32_t), c->stream));
   const int T = 256;
   if (N > 0) {
     {
@@ -492,7 +537,8 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
   {
     ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);
     hipLaunchKernelGGL(k_dec_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, q.keyv_s, q.keyr_s, N,
-                       V, R, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.rel_ptr, q.chunk_ptr);
+                       V, R, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
+                       q.piece_k, q.piece_cap, q.rel_ptr, q.chunk_ptr);
   }
   if (N > 0) {
     ProfScope ps(c, "dec_slots", 40.0 * N, 0);
@@ -528,6 +574,8 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     EntArgs a;
     a.codes = codes; a.Wr = Wr; a.dx = q.dx; a.row_ptr = q.row_ptr; a.e_other = q.e_other; a.e_rel = q.e_rel;
     a.e_trip = q.e_trip; a.long_rows = q.long_rows; a.nlong = q.nlong; a.dcodes = c->dcodes_own; a.V = V; a.d = d;
+    a.long_first = q.long_first; a.long_cnt = q.long_cnt; a.piece_row = q.piece_row; a.piece_k = q.piece_k;
+    a.piece_slab = q.piece_slab;
     a.k = k;
     const int nvec = vec4 ? d / 4 : d;
     const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
@@ -543,6 +591,8 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
       if (tpr == 64) RGCN_LAUNCH_EG(1, 64); else if (tpr == 128) RGCN_LAUNCH_EG(1, 128); else RGCN_LAUNCH_EG(1, 256);
     }
 #undef RGCN_LAUNCH_EG
+    if (vec4) hipLaunchKernelGGL((k_dec_long_finish<4>), dim3(128), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_dec_long_finish<1>), dim3(128), dim3(256), 0, c->stream, a);
   }
   {
     ProfScope ps(c, "dec_relation_grad", 8.0 * N * d + 8.0 * R * d, 3.0 * N * d);

@@ -358,6 +358,10 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   const int M = 2 * E;
   g.cur = tri;
   g.E = E;
+  // messages per relation chunk: 48 at minibatch scale, growing with THIS graph's size so that a full graph
+  // does not cut a popular relation into thousands of chunks (a context serves 15,000-edge training steps and
+  // the 272,115-edge evaluation pass alike); the capacity-scaled c->chunk is the upper bound the slabs are sized for
+  g.chunk = c->chunk_fixed ? c->chunk : std::min(c->chunk, 48 * (int)std::max<int64_t>(1, ((int64_t)M + 65535) / 65536));
   g.ready = false;
   g.pf_valid = false;
   c->fwd_done = false;
@@ -392,7 +396,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
     hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
-                       g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, c->chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
+                       g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
                        g.rel_ptr, g.chunk_ptr);
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {

@@ -219,7 +219,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   if (2 * f.max_edges > 65536) c->chunk = 48 * (int)((2 * f.max_edges + 65535) / 65536);
   if (const char* e = getenv("RGCN_CHUNK")) {
     const int v = atoi(e);
-    if (v >= 8 && v <= 4096) c->chunk = v;
+    if (v >= 8 && v <= 4096) { c->chunk = v; c->chunk_fixed = true; }
   }
   if (c->kind == RGCN_KIND_BLOCK) {
     c->nb = f.num_bases;
@@ -311,10 +311,13 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   }
   const size_t M = 2 * (size_t)f.max_edges;
   size_t slab = 64 * d * d;   // split-K slabs of the dW_self GEMM
+  // most relation chunks any graph that fits the context can have: the chunk size follows the graph's own size
+  // (graph_build), so a graph of 65536 messages cut at 48 can have more chunks than the largest graph cut coarser
+  const size_t max_rel_chunks = std::max((M + c->chunk - 1) / c->chunk, (std::min<size_t>(M, 65536) + 47) / 48) + 2 * R;
   if (c->kind == RGCN_KIND_BLOCK) {
     RGCN_TRY(dmalloc(c, &c->msgbuf, (M ? M : 1) * d, false));
     const size_t per_rel = (size_t)c->sd * c->sd * c->nb;
-    c->slab_dw_floats = ((M + c->chunk - 1) / c->chunk + 2 * R) * per_rel;
+    c->slab_dw_floats = max_rel_chunks * per_rel;
     RGCN_TRY(dmalloc(c, &c->slab_dw, c->slab_dw_floats, false));
   } else {
     const size_t zc = 2 * (size_t)c->B * d;
@@ -324,7 +327,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     for (int l = 1; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->zsave[l], V * zc));
     const size_t s2 = 16 * zc * d;
     if (s2 > slab) slab = s2;
-    c->slab_dw_floats = ((M + c->chunk - 1) / c->chunk + 2 * R) * (size_t)c->B;
+    c->slab_dw_floats = max_rel_chunks * (size_t)c->B;
     RGCN_TRY(dmalloc(c, &c->slab_dw, c->slab_dw_floats, false));
   }
   c->slab_floats = slab;

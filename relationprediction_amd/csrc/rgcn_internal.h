@@ -124,6 +124,7 @@ struct GraphBufs {
   int32_t* nlong = nullptr;     // device counter (lives in the zero-initialised counter block)
   int32_t long_cap = 0;
   int32_t* rel_ptr = nullptr;   // [2R+1]
+  int chunk = 48;               // messages per relation chunk of THIS graph (scales with its size)
   int32_t* chunk_ptr = nullptr; // [2R+1]
   int32_t* cum_in = nullptr;    // [V+1]  (tf_as_executed)
   int32_t* cum_out = nullptr;   // [V+1]
@@ -161,8 +162,11 @@ struct DecoderBufs {
   int32_t *valv = nullptr, *permv = nullptr, *valr = nullptr, *permr = nullptr;
   int32_t *row_ptr = nullptr, *rel_ptr = nullptr, *chunk_ptr = nullptr;
   int32_t *e_other = nullptr, *e_rel = nullptr, *e_trip = nullptr;
-  int32_t *long_rows = nullptr, *nlong = nullptr;
-  int32_t long_cap = 0, max_chunks = 0, energy_blocks = 0;
+  int32_t *long_rows = nullptr, *nlong = nullptr;     // nlong[0] = long rows, nlong[1] = their pieces
+  int32_t *long_first = nullptr, *long_cnt = nullptr;  // per long row: first piece id, number of pieces
+  int32_t *piece_row = nullptr, *piece_k = nullptr;    // per piece: its row, its index inside the row
+  float* piece_slab = nullptr;                         // [piece_cap][d] partial sums of the pieces
+  int32_t long_cap = 0, piece_cap = 0, max_chunks = 0, energy_blocks = 0;
   float *dx = nullptr, *loss_part = nullptr, *slab = nullptr;
   double* loss = nullptr;
   void* sort_tmp = nullptr;
@@ -224,7 +228,8 @@ struct rgcn_ctx {
   rgcn::GraphBufs g;                     // ACTIVE graph structures
   rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
   hipStream_t pf_stream = nullptr;       // stream of rgcn_prefetch_graph_device
-  int chunk = 48;                        // messages per relation chunk
+  bool chunk_fixed = false;              // RGCN_CHUNK in the environment pins the chunk size
+  int chunk = 48;                        // messages per relation chunk (capacity-scaled upper bound; GraphBufs::chunk is per graph)
   int gemm_mode = 0;                     // 0: fp32 MFMA; 3/6/9: bf16 split with that many partial products
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
 
