@@ -162,6 +162,56 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
         __syncthreads();
       }
     }
+    // giant rows (full-graph scale): one kGiantRow-slot PIECE per turn, partial sum to the piece slab; the
+    // finishing kernel adds the pieces of a row in order and applies prologue / epilogue
+    if (a.ngiant != nullptr) {
+      const int np = a.ngiant[1];
+      for (int b = blockIdx.x; b < np; b += n_long_blocks) {
+        const int v = a.piece_row[b];
+        const int beg = a.row_ptr[v] + a.piece_k[b] * kGiantRow;
+        const int end = min(a.row_ptr[v + 1], beg + kGiantRow);
+        for (int c0 = 0; c0 < nvec; c0 += 128) {
+          const int cidx = c0 + cl;
+          float acc[VEC];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+          if (cidx < nvec) {
+            const float* mp = a.msg + (size_t)cidx * VEC;
+            int s = beg + sl;
+            for (; s + 8 * 15 < end; s += 8 * 16) {
+              float m[16][VEC];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * a.d, m[u]);
+#pragma unroll
+              for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
+            }
+            for (; s < end; s += 8) {
+              float m0[VEC];
+              vload<VEC>(mp + (size_t)s * a.d, m0);
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+          __syncthreads();
+          if (sl == 0 && cidx < nvec) {
+            float tot[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              float t = red[0][cl * VEC + k];
+#pragma unroll
+              for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
+              tot[k] = t;
+            }
+            vstore<VEC>(a.giant_slab + (size_t)b * a.d + (size_t)cidx * VEC, tot);
+          }
+          __syncthreads();
+        }
+      }
+    }
     return;
   }
   const int rows_per_block = kCombineThreads / TPR;
@@ -196,6 +246,31 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
       for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
     }
     combine_epilogue<VEC>(a, off, acc);
+  }
+}
+
+// giant rows: prologue + pieces in piece order + epilogue
+template <int VEC>
+__global__ void __launch_bounds__(256) k_combine_giant_finish(CombineArgs a) {
+  const int nvec = a.d / VEC;
+  const int n = a.ngiant[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int v = a.giant_rows[i], first = a.giant_first[i], cnt = a.giant_cnt[i];
+    for (int cidx = threadIdx.x; cidx < nvec; cidx += 256) {
+      const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+      float tot[VEC], sum[VEC], part[VEC];
+      combine_prologue<VEC>(a, v, off, tot);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) sum[k] = 0.0f;
+      for (int p = 0; p < cnt; ++p) {
+        vload<VEC>(a.giant_slab + (size_t)(first + p) * a.d + (size_t)cidx * VEC, part);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sum[k] += part[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tot[k] += sum[k];
+      combine_epilogue<VEC>(a, off, tot);
+    }
   }
 }
 
@@ -317,8 +392,15 @@ DropSpec make_drop(const rgcn_ctx* c, int layer, bool active) {
   return ds;
 }
 
-rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes) {
-  if (a.V <= 0) return RGCN_OK;
+rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a_in, double alg_bytes) {
+  if (a_in.V <= 0) return RGCN_OK;
+  CombineArgs a = a_in;
+  const bool giant = a.msg != nullptr && a.row_ptr == c->g.row_ptr && c->g.giant_on;
+  if (giant) {
+    if (!c->giant_slab) RGCN_HIP(c, hipMalloc((void**)&c->giant_slab, sizeof(float) * (size_t)c->g.piece_cap * c->d));
+    a.giant_rows = c->g.giant_rows; a.giant_first = c->g.giant_first; a.giant_cnt = c->g.giant_cnt;
+    a.piece_row = c->g.piece_row; a.piece_k = c->g.piece_k; a.ngiant = c->g.ngiant; a.giant_slab = c->giant_slab;
+  }
   const bool vec4 = (a.d % 4 == 0) && aligned16(a.out) && aligned16(a.base) && aligned16(a.msg) && aligned16(a.add) &&
                     aligned16(a.gate) && aligned16(a.out2);
   const int nvec = vec4 ? a.d / 4 : a.d;
@@ -345,6 +427,10 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double a
     else RGCN_LAUNCH_COMBINE(1, 256);
   }
 #undef RGCN_LAUNCH_COMBINE
+  if (giant) {
+    if (vec4) hipLaunchKernelGGL((k_combine_giant_finish<4>), dim3(64), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_combine_giant_finish<1>), dim3(64), dim3(256), 0, c->stream, a);
+  }
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

@@ -132,8 +132,10 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
                                                const int32_t* __restrict__ permv, int E, int degrees_from_rows,
                                                int32_t* indeg, int32_t* outdeg, int M, int V, int R2,
                                                int chunk, int32_t* row_ptr,
-                                               int32_t* long_rows, int32_t* nlong, int cap, int32_t* rel_ptr,
-                                               int32_t* chunk_ptr) {
+                                               int32_t* long_rows, int32_t* nlong, int cap, int giant_threshold,
+                                               int32_t* giant_rows, int32_t* giant_first, int32_t* giant_cnt,
+                                               int32_t* piece_row, int32_t* piece_k, int32_t* ngiant, int giant_cap,
+                                               int piece_cap, int32_t* rel_ptr, int32_t* chunk_ptr) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -189,7 +191,15 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
     indeg[v] = lo - beg;
     outdeg[v] = end - lo;
   }
-  if (end - beg > kLongRow) {
+  if (end - beg > giant_threshold) {
+    // pieces of one row get consecutive ids: the finishing pass adds them in a fixed order
+    const int np = (end - beg + kGiantRow - 1) / kGiantRow;
+    const int i = atomicAdd(ngiant, 1);
+    const int base = atomicAdd(ngiant + 1, np);
+    if (i < giant_cap) { giant_rows[i] = v; giant_first[i] = base; giant_cnt[i] = np; }
+    for (int k = 0; k < np; ++k)
+      if (base + k < piece_cap) { piece_row[base + k] = v; piece_k[base + k] = k; }
+  } else if (end - beg > kLongRow) {
     const int i = atomicAdd(nlong, 1);
     if (i < cap) long_rows[i] = v;
   }
@@ -271,11 +281,19 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   GraphBufs& g = c->g;
   const size_t V = c->V, R2 = 2 * (size_t)c->R, M = 2 * (size_t)c->cfg.max_edges;
   RGCN_TRY(dalloc(c, &g.triples, 3 * (size_t)c->cfg.max_edges));
-  g.counters_bytes = (2 * V + 1) * sizeof(int32_t);
-  RGCN_TRY(dalloc(c, &g.counters, 2 * V + 1));
+  g.counters_bytes = (2 * V + 3) * sizeof(int32_t);
+  RGCN_TRY(dalloc(c, &g.counters, 2 * V + 3));
   g.indeg = g.counters;
   g.outdeg = g.counters + V;
   g.nlong = g.counters + 2 * V;
+  g.ngiant = g.counters + 2 * V + 1;
+  g.giant_cap = (int32_t)(M / kGiantRow + 1);
+  g.piece_cap = (int32_t)(2 * (M / kGiantRow) + 2);
+  RGCN_TRY(dalloc(c, &g.giant_rows, (size_t)g.giant_cap));
+  RGCN_TRY(dalloc(c, &g.giant_first, (size_t)g.giant_cap));
+  RGCN_TRY(dalloc(c, &g.giant_cnt, (size_t)g.giant_cap));
+  RGCN_TRY(dalloc(c, &g.piece_row, (size_t)g.piece_cap));
+  RGCN_TRY(dalloc(c, &g.piece_k, (size_t)g.piece_cap));
   g.long_cap = (int32_t)(M / kLongRow + 1);
   RGCN_TRY(dalloc(c, &g.long_rows, (size_t)g.long_cap));
   RGCN_TRY(dalloc(c, &g.row_ptr, V + 1));
@@ -337,7 +355,7 @@ static void graph_free_one(GraphBufs& g, bool owns_shared) {
   if (!owns_shared) { g.owner = nullptr; g.errflag = nullptr; }
   if (g.ev_ready) (void)hipEventDestroy(g.ev_ready);
   if (g.ev_free) (void)hipEventDestroy(g.ev_free);
-  void* ptrs[] = {g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
+  void* ptrs[] = {g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row, g.piece_k, g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel,
                   g.s_norm, g.owner, g.errflag, g.sort_tmp,
@@ -362,6 +380,9 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   // does not cut a popular relation into thousands of chunks (a context serves 15,000-edge training steps and
   // the 272,115-edge evaluation pass alike); the capacity-scaled c->chunk is the upper bound the slabs are sized for
   g.chunk = c->chunk_fixed ? c->chunk : std::min(c->chunk, 48 * (int)std::max<int64_t>(1, ((int64_t)M + 65535) / 65536));
+  // giant-row cut: full-graph scale, block kind, one GPU (the basis gathers and the sharded finish walk the long-row
+  // list themselves)
+  g.giant_on = c->kind == RGCN_KIND_BLOCK && c->world == 1 && M > 65536;
   g.ready = false;
   g.pf_valid = false;
   c->fwd_done = false;
@@ -397,7 +418,8 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
     hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
                        g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
-                       g.rel_ptr, g.chunk_ptr);
+                       g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
+                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr);
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
     ScanJobs jobs;

@@ -172,6 +172,7 @@ static void free_all(rgcn_ctx* c) {
   decoder_free(c);
   optimizer_free(c);
   rank_free(c);
+  if (c->giant_slab) (void)hipFree(c->giant_slab);
   F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb); F(c->w_rel); F(c->g_rel);
   for (LayerBufs& lb : c->layers) {
     F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);

@@ -57,6 +57,9 @@ enum DropMode { DROP_NONE = 0, DROP_RNG = 1, DROP_MASK = 2 };
 // Rows of the incidence CSR with more slots than this are pre-reduced by a whole workgroup
 // (k_long_row_reduce) so that the one-wave-group-per-row combine never walks a hub serially.
 constexpr int kLongRow = 32;
+// Full-graph scale only (more than 65536 messages, block kind): a row with more than kGiantRow slots is cut into
+// kGiantRow-slot pieces that separate workgroups sum; a finishing pass adds a row's pieces in piece order.
+constexpr int kGiantRow = 2048;
 
 struct DropSpec {
   int32_t mode;         // DropMode
@@ -120,7 +123,13 @@ struct GraphBufs {
   int32_t* counters = nullptr;  // base of the zero-initialised block (indeg, outdeg, nlong)
   size_t counters_bytes = 0;
   int32_t* row_ptr = nullptr;   // [V+1]
-  int32_t* long_rows = nullptr; // compacted list of rows with more than kLongRow slots
+  int32_t* long_rows = nullptr; // compacted list of rows with more than kLongRow slots (and at most the giant threshold)
+  // giant rows: per row its first piece id and piece count; per piece its row and its index inside the row;
+  // ngiant[0] = rows, ngiant[1] = pieces (device counters in the zero-initialised block)
+  int32_t *giant_rows = nullptr, *giant_first = nullptr, *giant_cnt = nullptr, *piece_row = nullptr, *piece_k = nullptr;
+  int32_t* ngiant = nullptr;
+  int32_t giant_cap = 0, piece_cap = 0;
+  bool giant_on = false;        // this graph was prepared with the giant-row cut enabled
   int32_t* nlong = nullptr;     // device counter (lives in the zero-initialised counter block)
   int32_t long_cap = 0;
   int32_t* rel_ptr = nullptr;   // [2R+1]
@@ -249,6 +258,7 @@ struct rgcn_ctx {
   bool step_begin_in_capture = false;
   std::vector<hipGraphExec_t> graphs;
   std::vector<hipGraph_t> graph_defs;
+  float* giant_slab = nullptr;           // [piece_cap][d] partial sums of giant-row pieces (scratch of one combine launch)
   float *rank_q = nullptr, *rank_s = nullptr;   // ranking: query rows [max,d], energies [max,V]
   int32_t* rank_bad = nullptr;
   int64_t rank_max = 0;
@@ -330,6 +340,14 @@ struct CombineArgs {
   const int32_t* row_ptr;
   const int32_t* long_rows; // rows with more than kLongRow slots (GraphBufs::long_rows / nlong)
   const int32_t* nlong;
+  // giant rows (GraphBufs; all null when the cut is off)
+  const int32_t* giant_rows = nullptr;
+  const int32_t* giant_first = nullptr;
+  const int32_t* giant_cnt = nullptr;
+  const int32_t* piece_row = nullptr;
+  const int32_t* piece_k = nullptr;
+  const int32_t* ngiant = nullptr;
+  float* giant_slab = nullptr;  // [pieces][d]
   const float* gate;     // optional: result *= (gate > 0)
   int32_t V, d;
   int32_t relu;
