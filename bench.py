@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fb237_block", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=4, help="timed CPU-oracle steps (0 disables)")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay the steps from a captured hipGraph (two steps + their prefetches per launch; "
