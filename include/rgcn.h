@@ -192,6 +192,14 @@ void rgcn_sampler_destroy(rgcn_sampler* sampler);
 rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* sampler, int64_t sample_size, uint64_t seed,
                                            int32_t* out_edge_ids);
 
+/* NegativeSampler.transform (code/common/auxilliaries.py:13-33) on the device: x_out = int32 [n*(rate+1), 3], the batch
+ * tiled rate+1 times with, in every row after the first n, the object (fair coin) or else the subject replaced by a
+ * uniform entity id; y_out = float32 [n*(rate+1)], 1 for the first n rows, 0 after.  Same layout and distribution as
+ * the reference's numpy code, other random stream (counter-based, a function of `seed`).  Ids of `batch` are NOT
+ * validated here; the decoder rejects out-of-range ids when it consumes x_out.  Asynchronous, capturable. */
+rgcn_status rgcn_negative_sample_device(rgcn_ctx* ctx, const int32_t* batch_dev, int64_t n, int32_t rate, uint64_t seed,
+                                        int32_t* x_out_dev, float* y_out_dev);
+
 /* ---- evaluation: raw and filtered link-prediction ranks -------------------------------
  * Replaces Model.score_all_subjects / score_all_objects + Scorer.evaluate_mrr + MrrScore.append_line
  * (code/model.py:59-81, code/decoders/bilinear_diag.py:51-61, code/common/evaluation.py:148-153,349-389).

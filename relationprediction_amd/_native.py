@@ -76,6 +76,7 @@ _SIGS = {
     "rgcn_capture_end": (C.c_int32, [_P, C.POINTER(C.c_int32)]),
     "rgcn_graph_launch": (C.c_int32, [_P, C.c_int32]),
     "rgcn_graph_destroy": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_negative_sample_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_uint64, _P, _P]),
     "rgcn_rank_reserve": (C.c_int32, [_P, C.c_int64]),
     "rgcn_rank_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "rgcn_optimizer_step": (C.c_int32, [_P]),
@@ -395,6 +396,11 @@ class Engine:
 
     def graph_destroy(self, graph_id):
         self._check(self.lib.rgcn_graph_destroy(self.ctx, int(graph_id)))
+
+    def negative_sample_device(self, batch_dev, n, rate, seed, x_dev, y_dev):
+        """X [n*(rate+1),3] and Y [n*(rate+1)] from the batch of n triples, all on the device."""
+        self._check(self.lib.rgcn_negative_sample_device(self.ctx, batch_dev.ptr, int(n), int(rate), C.c_uint64(int(seed)),
+                                                         x_dev.ptr, y_dev.ptr))
 
     def rank_reserve(self, max_queries):
         self._check(self.lib.rgcn_rank_reserve(self.ctx, int(max_queries)))

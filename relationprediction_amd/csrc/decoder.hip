@@ -144,6 +144,29 @@ __global__ void k_dec_slots(const int32_t* __restrict__ X, int N, const int32_t*
   e_trip[s] = n;
 }
 
+// ---- negative sampling on the device ------------------------------------------------
+// NegativeSampler.transform (code/common/auxilliaries.py:13-33): the batch tiled (rate + 1) times, labels 1 for the
+// first copy and 0 after it; every further row has its object (fair coin) or else its subject replaced by a uniformly
+// drawn entity.  Same layout and distribution, counter-based generator instead of numpy's streams.
+__global__ void k_negative_sample(const int32_t* __restrict__ batch, int n, int rate, int num_entities, uint64_t seed,
+                                  int32_t* __restrict__ X, float* __restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n * (rate + 1);
+  if (i >= total) return;
+  const int b = (int)(i % n);
+  int s = batch[3 * b], r = batch[3 * b + 1], o = batch[3 * b + 2];
+  if (i >= n) {
+    const uint64_t j = (uint64_t)(i - n);
+    const uint32_t coin = drop_bits(seed, 0x6e65u, 2 * j);            // 24 random bits
+    const uint32_t a = drop_bits(seed, 0x6e66u, 2 * j), c = drop_bits(seed, 0x6e67u, 2 * j + 1);
+    const uint64_t u = ((uint64_t)a << 24) | c;                        // 48 random bits
+    const int32_t ent = (int32_t)((u * (uint64_t)num_entities) >> 48); // uniform in [0, num_entities)
+    if (coin & 1u) o = ent; else s = ent;
+  }
+  X[3 * i] = s; X[3 * i + 1] = r; X[3 * i + 2] = o;
+  Y[i] = i < n ? 1.0f : 0.0f;
+}
+
 // ---- K1: energies, dx, loss terms ---------------------------------------------------------------
 template <int VEC>
 __global__ void __launch_bounds__(256) k_dec_energy(const float* __restrict__ codes, const float* __restrict__ Wr,
@@ -453,6 +476,17 @@ rgcn_status dalloc(rgcn_ctx* c, T** p, size_t n) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
+
+rgcn_status negative_sample(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int rate, uint64_t seed, int32_t* X,
+                            float* Y) {
+  const int64_t total = n * (rate + 1);
+  if (total <= 0) return RGCN_OK;
+  ProfScope ps(c, "negative_sample", 12.0 * n + 16.0 * total, 0);
+  hipLaunchKernelGGL(k_negative_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, batch_dev,
+                     (int)n, rate, c->V, seed, X, Y);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
 
 rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   DecoderBufs& q = c->dec;

@@ -816,6 +816,15 @@ rgcn_status rgcn_get_loss(rgcn_ctx* c, double* loss) {
   return to_host(c, loss, c->dec.loss, sizeof(double));
 }
 
+rgcn_status rgcn_negative_sample_device(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int32_t rate, uint64_t seed,
+                                        int32_t* x_out_dev, float* y_out_dev) {
+  RGCN_NEED(c);
+  if (n < 0 || rate < 0 || rate > 1024 || (n > 0 && (!batch_dev || !x_out_dev || !y_out_dev)))
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  if (n * (int64_t)(rate + 1) > ((int64_t)1 << 30)) RGCN_FAIL(c, RGCN_ERR_INVALID, "batch too large");
+  return negative_sample(c, batch_dev, n, rate, seed, x_out_dev, y_out_dev);
+}
+
 rgcn_status rgcn_rank_reserve(rgcn_ctx* c, int64_t max_queries) {
   RGCN_NEED(c);
   if (max_queries <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "max_queries must be positive");

@@ -365,6 +365,8 @@ rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, 
 DropSpec make_drop(const rgcn_ctx* c, int layer, bool active);
 
 // ---- decoder.hip / optimizer.hip
+rgcn_status negative_sample(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int rate, uint64_t seed, int32_t* X,
+                            float* Y);
 rgcn_status decoder_reserve(rgcn_ctx* c, int64_t max_triples);
 void decoder_free(rgcn_ctx* c);
 rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N);

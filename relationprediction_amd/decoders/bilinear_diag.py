@@ -79,6 +79,11 @@ class BilinearDiag(Model):
         """loss + regularisation, all gradients, clip and Adam in one asynchronous device step."""
         self.next_component.get_runtime().train_step(graph_edges, x, y, self.regularization_parameter, seed)
 
+    def device_train_step_negatives(self, graph_edges, batch, rate, seed):
+        """device_train_step with the negatives drawn on the device from `batch`."""
+        self.next_component.get_runtime().train_step_device_negatives(graph_edges, batch, rate,
+                                                                      self.regularization_parameter, seed)
+
     def device_loss(self):
         return self.next_component.get_runtime().loss()
 

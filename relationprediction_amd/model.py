@@ -182,6 +182,9 @@ class Model(object):
     def device_train_step(self, *args):
         return self.__delegate__('device_train_step', *args)
 
+    def device_train_step_negatives(self, *args):
+        return self.__delegate__('device_train_step_negatives', *args)
+
     def device_loss(self):
         return self.__delegate__('device_loss')
 

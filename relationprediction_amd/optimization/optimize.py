@@ -239,6 +239,14 @@ def build_stack(parameters):
     return stack
 
 
+class DeviceNegatives(object):
+    """A processed batch whose decoder triples are still to be drawn — on the device, at step time — from
+    `batch` (NegativeSampler.transform's distribution: rgcn_negative_sample_device)."""
+
+    def __init__(self, graph_edges, batch, rate):
+        self.graph_edges, self.batch, self.rate = graph_edges, batch, int(rate)
+
+
 class HipOptimizer(object):
     """TensorflowOptimizer's role (optimize.py:42-90) on the device train step."""
 
@@ -255,6 +263,10 @@ class HipOptimizer(object):
 
     def update_from_batch(self, processed_batch, seed):
         """Enqueue one train step; processed_batch = (graph_edges, X, Y) as the transform function returns."""
+        if isinstance(processed_batch, DeviceNegatives):
+            self.model.device_train_step_negatives(processed_batch.graph_edges, processed_batch.batch,
+                                                   processed_batch.rate, seed)
+            return
         graph_edges, x, y = processed_batch
         self.model.device_train_step(graph_edges, x, y, seed)
 

@@ -121,6 +121,34 @@ class EncoderRuntime(object):
         self._graph_version = None
         self.weights_version += 1
 
+    def train_step_device_negatives(self, graph_edges, batch, rate, reg_param, seed):
+        """As train_step, with the decoder batch (positives + `rate` corruptions each) drawn on the device from
+        `batch` (rgcn_negative_sample_device): only the two triple lists cross the PCIe bus."""
+        g = np.ascontiguousarray(graph_edges, dtype=np.int32).reshape(-1, 3)
+        b = np.ascontiguousarray(batch, dtype=np.int32).reshape(-1, 3)
+        n = len(b) * (int(rate) + 1)
+        if n == 0:
+            raise ValueError("empty decoder batch")
+        if len(g) > self.engine.max_edges:
+            raise ValueError("graph batch of %d edges exceeds the context's max_edges %d"
+                             % (len(g), self.engine.max_edges))
+        if n > self._dec_reserved:
+            self.engine.decoder_reserve(n)
+            self._dec_reserved = n
+        gd, bd = self._upload("graph", g), self._upload("batch", b)
+        for name, nbytes in (("X", 12 * n), ("Y", 4 * n)):
+            buf = self._dev.get(name)
+            if buf is None or buf.nbytes < nbytes:
+                if buf is not None:
+                    buf.free()
+                self._dev[name] = _native.DeviceBuffer(self.engine, nbytes)
+        xd, yd = self._dev["X"], self._dev["Y"]
+        self.engine.negative_sample_device(bd, len(b), rate, seed ^ 0x5bd1e995, xd, yd)
+        self.engine.train_step_device(gd, len(g), xd, yd, n, seed=seed, reg_param=reg_param)
+        self._state = None
+        self._graph_version = None
+        self.weights_version += 1
+
     def loss(self):
         return self.engine.loss()
 

@@ -29,7 +29,7 @@ def load_dataset(dataset, metric='MRR'):
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
 
-def make_transform(train_triplets, general_settings, encoder):
+def make_transform(train_triplets, general_settings, encoder, device_negatives=False):
     """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y).
 
     Every batch is a function of ONE seed drawn from numpy's global generator when the batch is requested, so
@@ -58,6 +58,9 @@ def make_transform(train_triplets, general_settings, encoder):
         split_size = int(float(general_settings['GraphSplitSize']) * graph_batch.shape[0])
         graph_split_ids = rng.choice(graph_batch_ids, size=split_size, replace=False)
         graph_split = train_triplets[graph_split_ids]
+        if device_negatives:          # corruptions are drawn by the device step (optimize.DeviceNegatives)
+            from .optimization.optimize import DeviceNegatives
+            return DeviceNegatives(graph_split, graph_batch, ns.negative_sample_rate)
         t = ns.transform(graph_batch, rng)
         return (graph_split, t[0], t[1])
 
@@ -74,6 +77,8 @@ def main(argv=None):
     parser.add_argument("--dataset", help="Filepath for dataset.", required=True)
     parser.add_argument("--max-iterations", type=int, default=None,
                         help="stop after this many iterations (sets Optimizer.MaxIterations)")
+    parser.add_argument("--host-negatives", action="store_true",
+                        help="draw the negative samples with the reference's numpy code on the host instead of on the device")
     parser.add_argument("--batch-workers", type=int, default=8,
                         help="background threads that build minibatches ahead of the device (0: build in line)")
     args = parser.parse_args(argv)
@@ -128,7 +133,8 @@ def main(argv=None):
     print(len(train_triplets))
 
     if 'NegativeSampleRate' in general_settings:
-        opp.set_sample_transform_function(make_transform(train_triplets, general_settings, encoder))
+        opp.set_sample_transform_function(make_transform(train_triplets, general_settings, encoder,
+                                                         device_negatives=not args.host_negatives))
 
     model.preprocess(train_triplets)
     model.register_for_test(train_triplets)

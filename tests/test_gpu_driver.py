@@ -77,8 +77,8 @@ def write_dataset(root, V=200, R=6, n_train=700, seed=0):
     return triples[:n_train]
 
 
-@pytest.mark.parametrize("concat,nb", [("Yes", 4), ("No", 2)])
-def test_train_driver_end_to_end(tmp_path, capsys, concat, nb):
+@pytest.mark.parametrize("concat,nb,extra", [("Yes", 4, []), ("No", 2, []), ("Yes", 4, ["--host-negatives", "--batch-workers", "0"])])
+def test_train_driver_end_to_end(tmp_path, capsys, concat, nb, extra):
     from relationprediction_amd import train
     data = str(tmp_path / "data")
     train_triples = write_dataset(data)
@@ -87,7 +87,7 @@ def test_train_driver_end_to_end(tmp_path, capsys, concat, nb):
     settings = tmp_path / "toy.exp"
     settings.write_text(SETTINGS % dict(nb=nb, concat=concat, exp=exp))
     np.random.seed(0)
-    model, iterations = train.main(["--settings", str(settings), "--dataset", data, "--max-iterations", "60"])
+    model, iterations = train.main(["--settings", str(settings), "--dataset", data, "--max-iterations", "60"] + extra)
     out = capsys.readouterr().out
     assert iterations == 60
     losses = [float(l.split(": ")[-1]) for l in out.splitlines() if l.startswith("Average train loss")]

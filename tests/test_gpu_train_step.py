@@ -122,3 +122,44 @@ def test_train_step_device_with_clip_and_adam(native, kind, nb):
             b.free()
     finally:
         eng.close()
+
+
+def test_device_negative_sampler_layout_and_distribution(native):
+    """rgcn_negative_sample_device against the definition of NegativeSampler.transform
+    (code/common/auxilliaries.py:13-33): tiling order, labels, which column may change, uniform replacements."""
+    V, R, n, rate = 500, 7, 4000, 10
+    rng = np.random.RandomState(0)
+    batch = np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1).astype(np.int32)
+    eng = native.Engine(V, R, 8, 1, "block", 2, max_edges=16)
+    try:
+        bd = eng.to_device(batch)
+        total = n * (rate + 1)
+        xd, yd = native.DeviceBuffer(eng, 12 * total), native.DeviceBuffer(eng, 4 * total)
+        eng.negative_sample_device(bd, n, rate, 123, xd, yd)
+        X, Y = xd.download(np.int32, (total, 3)), yd.download(np.float32, (total,))
+        eng.negative_sample_device(bd, n, rate, 123, xd, yd)
+        assert np.array_equal(X, xd.download(np.int32, (total, 3)))            # a function of the seed
+        eng.negative_sample_device(bd, n, rate, 124, xd, yd)
+        assert not np.array_equal(X, xd.download(np.int32, (total, 3)))
+        for b in (bd, xd, yd):
+            b.free()
+    finally:
+        eng.close()
+    assert (Y[:n] == 1).all() and (Y[n:] == 0).all()
+    assert np.array_equal(X[:n], batch)
+    tiled = np.tile(batch, (rate, 1))
+    neg = X[n:]
+    assert np.array_equal(neg[:, 1], tiled[:, 1])                              # relations never change
+    subj_changed, obj_changed = neg[:, 0] != tiled[:, 0], neg[:, 2] != tiled[:, 2]
+    assert not (subj_changed & obj_changed).any()                              # one side per row
+    assert (neg[:, [0, 2]] >= 0).all() and (neg[:, [0, 2]] < V).all()
+    # fair coin (a replacement can draw the original id: 1/V of the rows look unchanged)
+    frac_obj = obj_changed.sum() / float((subj_changed | obj_changed).sum())
+    assert abs(frac_obj - 0.5) < 0.01
+    assert abs((subj_changed | obj_changed).mean() - (1 - 1.0 / V)) < 0.005
+    # replacements are uniform over the entities: chi-square against the flat histogram
+    repl = np.concatenate([neg[subj_changed, 0], neg[obj_changed, 2]])
+    counts = np.bincount(repl, minlength=V).astype(np.float64)
+    expected = len(repl) / float(V)
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert abs(chi2 - V) < 5 * np.sqrt(2 * V), chi2

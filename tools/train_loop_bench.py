@@ -51,7 +51,7 @@ SETTINGS = """[Encoder]
 
 
 def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 40
     V, R, E = 14541, 237, 272115
     triples = oracle.synthetic_graph(V, R, E, np.random.RandomState(0)).astype(np.int32)
     path = "/tmp/rgcn_train_loop_bench.exp"
@@ -67,7 +67,7 @@ def main():
     model = model_builder.build_decoder(encoder, s['Decoder'])
     opp = optimizer_parameter_parser.Parser(s['Optimizer'])
     opp.set_save_function(lambda p: None)
-    t_func = train.make_transform(triples, general, encoder)
+    t_func = train.make_transform(triples, general, encoder, device_negatives="--host-negatives" not in sys.argv)
     host_times = []
 
     def timed(x):
