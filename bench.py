@@ -35,6 +35,8 @@ WORKLOADS = {
     "fb237_block": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 15000),
     "fb237_block_fullgraph": ("fb237_valid_test", 14541, 237, 500, 2, "block", 100, 38001),
     "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
+    # BASELINE.json configs[3]'s shape on one GPU: WN18 (V 40,943 / R 18), the 10,000 real valid+test triples as graph
+    "wn18_block": ("wn18_valid_test", 40943, 18, 500, 2, "block", 100, 10000),
     # BASELINE.json configs[2]: basis decomposition, B = 2 (and settings/gcn_basis.exp's own B = 5)
     "fb237_basis_b2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 15000),
     "fb237_basis_b5": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 5, 15000),
@@ -296,7 +298,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "processed edges/sec (R-GCN forward+backward), FB15k-237 gcn_%s" % kind,
+            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % ("WN18" if args.workload.startswith("wn18") else "Toy" if args.workload.startswith("toy") else "FB15k-237", kind),
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,

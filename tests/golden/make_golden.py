@@ -5,7 +5,8 @@
 graphs.npz   real graph structure read from the reference's data files with the reference's own
              file formats (code/common/io.py:5-39): Toy train (43 triples, complete) and the
              FB15k-237 minibatch of SURVEY.md 8d config 2 "graph A" (30,000 of the 38,001 valid+test
-             triples, seed 0, no replacement; then a random 15,000 of them = GraphSplitSize 0.5).
+             triples, seed 0, no replacement; then a random 15,000 of them = GraphSplitSize 0.5); the 10,000 WN18
+             valid+test triples (config 4's entity / relation space: 40,943 / 18).
 expected.npz fingerprints (l2 norm, sum, 256 sampled entries) of the ORACLE's outputs on the cases
              in tests/helpers.py:GOLDEN_CASES.  The reference ships no golden vectors and TF 1.4
              cannot run here ("parity unpinned"), so these pin the oracle against regressions and
@@ -55,8 +56,13 @@ def make_graphs():
     rng = np.random.default_rng(0)
     batch = rng.choice(fb.shape[0], size=30000, replace=False)
     split = rng.choice(batch, size=15000, replace=False)
+    ent = read_dictionary(REF + "/wn18/entities.dict")
+    rel = read_dictionary(REF + "/wn18/relations.dict")
+    wn = np.concatenate([read_triples(REF + "/wn18/valid.txt", ent, rel),
+                         read_triples(REF + "/wn18/test.txt", ent, rel)], axis=0)
+    assert wn.shape == (10000, 3) and len(ent) == 40943 and len(rel) == 18
     np.savez_compressed(os.path.join(HERE, "graphs.npz"), toy_train=toy, fb237_minibatch=fb[split],
-                        fb237_valid_test=fb)
+                        fb237_valid_test=fb, wn18_valid_test=wn)
 
 
 def make_expected():
@@ -80,4 +86,5 @@ def make_expected():
 if __name__ == "__main__":
     if os.path.isdir(REF):
         make_graphs()
-    make_expected()
+    if "--graphs-only" not in sys.argv:
+        make_expected()

@@ -420,6 +420,26 @@ def test_full_graph_inference_shape(native):
     assert float(np.abs(codes - oacts[-1]).max()) <= FWD_ATOL
 
 
+def test_wn18_shape_forward_parity(native):
+    """BASELINE config 4's entity / relation space on one GPU: WN18 (V 40,943, R 18; top-3 relations hold 70 %
+    of the edges), the 10,000 real valid+test triples as graph, d = 500, block kind, train mode with injected masks."""
+    V, R, d, L, nb = 40943, 18, 500, 2, 100
+    triples = helpers.load_graph("wn18_valid_test")
+    rng = np.random.RandomState(11)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    masks = [(rng.rand(V, d) < 0.8).astype(np.uint8) for _ in range(L)]
+    oacts = oracle.encoder_forward(params, triples, V, L, "block", mode="train", keep_prob=0.8, dropout_masks=masks)
+    eng = native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=len(triples))
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, masks=masks)
+        for l in range(L + 1):
+            assert float(np.abs(eng.activation(l) - oacts[l]).max()) <= FWD_ATOL, l
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------ relation sharding on one GPU
 @pytest.mark.parametrize("world", [2, 4])
 def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4):
