@@ -291,11 +291,19 @@ __global__ void k_input_fwd(const float* __restrict__ W, const float* __restrict
   }
 }
 
-__global__ void k_scale_dropout(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+template <int VEC>
+__global__ void k_scale_dropout(const float* __restrict__ in, float* __restrict__ out, int64_t nvec,
                                 DropSpec ds) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = in[i] * drop_scale(ds, (size_t)i);
+  for (; i < nvec; i += stride) {
+    const size_t off = (size_t)i * VEC;
+    float v[VEC];
+    vload<VEC>(in + off, v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] *= drop_scale(ds, off + k);
+    vstore<VEC>(out + off, v);
+  }
 }
 
 __global__ void k_relu_copy(const float* __restrict__ in, float* __restrict__ out, int64_t n, int relu) {
@@ -452,7 +460,10 @@ rgcn_status input_forward(rgcn_ctx* c) {
 rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds) {
   const int64_t n = (int64_t)c->V * c->d;
   ProfScope ps(c, "top_grad_dropout", 8.0 * n, 0);
-  hipLaunchKernelGGL(k_scale_dropout, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, in, out, n, ds);
+  if (n % 4 == 0 && aligned16(in) && aligned16(out))
+    hipLaunchKernelGGL((k_scale_dropout<4>), dim3(grid_for(n / 4, 256)), dim3(256), 0, c->stream, in, out, n / 4, ds);
+  else
+    hipLaunchKernelGGL((k_scale_dropout<1>), dim3(grid_for(n, 256)), dim3(256), 0, c->stream, in, out, n, ds);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

@@ -260,15 +260,43 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
     }
 }
 
+// slabs are added in slab order (fixed summation order); VEC = 4: 16-byte accesses, 8 slab loads in flight
+template <int VEC>
 __global__ void k_splitk_reduce(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
                                 int ldc, int splits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   const int64_t mn = (int64_t)M * N;
   if (i >= mn) return;
-  float acc = 0.0f;
-  for (int s = 0; s < splits; ++s) acc += slab[(size_t)s * mn + i];
-  const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
-  C[(size_t)row * ldc + col] = acc;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+    float v[8][VEC];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* p = slab + (size_t)(s + u) * mn + i;
+      if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+      } else {
+        v[u][0] = *p;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += v[u][k];
+  }
+  for (; s < splits; ++s)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += slab[(size_t)s * mn + i + k];
+  const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);     // N % VEC == 0: the VEC elements share a row
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    C[(size_t)row * ldc + col] = acc[0];
+  }
 }
 
 // 16-byte loads legal and float4 validity all-or-nothing: aligned base, ld % 4 == 0, and the
@@ -346,8 +374,12 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   if (slabs) {
     const int64_t mn = (int64_t)M * N;
     ProfScope ps(c, "splitk_reduce", 4.0 * mn * (split_k + 1), 0);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, c->stream,
-                       c->slab, C, M, N, ldc, split_k);
+    if (N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0)
+      hipLaunchKernelGGL((k_splitk_reduce<4>), dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, c->stream,
+                         c->slab, C, M, N, ldc, split_k);
+    else
+      hipLaunchKernelGGL((k_splitk_reduce<1>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, c->stream,
+                         c->slab, C, M, N, ldc, split_k);
     RGCN_HIP(c, hipGetLastError());
   }
   return RGCN_OK;
