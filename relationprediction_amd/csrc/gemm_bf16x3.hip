@@ -225,7 +225,7 @@ __device__ __forceinline__ bf16x8 load_frag(const uint32_t* __restrict__ plane, 
 }
 
 // ABL: compile-time ablations for tools/gemm_modes.py (1 no in-loop global loads, 2 no split/store,
-// 8 no fragment reads, 16 no barrier, 32 no MFMA); results are garbage, only the timing means anything.
+// 8 no fragment reads, 16 no barrier, 32 no MFMA, 64 no conversion / LDS store of operand B); results are garbage, only the timing means anything.
 template <bool A_KC, bool B_KC, bool VEC, int TERMS, int ABL = 0>
 __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   constexpr int PA = A_KC ? KC_PLANE : RC_PLANE, PB = B_KC ? KC_PLANE : RC_PLANE;
@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
       constexpr int c0 = m * PER < 24 ? m * PER : 24, c1 = (m + 1) * PER < 24 ? (m + 1) * PER : 24;
       if constexpr (!(ABL & 2)) {
         split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt);
-        split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
+        if constexpr (!(ABL & 64))    // 64: operand B costs nothing (upper bound of what a pre-split W could save)
+          split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -500,6 +501,7 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
       case 27: return launch_one<true, true, true, 6, 27>(c, g);
       case 32: return launch_one<true, true, true, 6, 32>(c, g);
       case 59: return launch_one<true, true, true, 6, 59>(c, g);
+      case 64: return launch_one<true, true, true, 6, 64>(c, g);
 
       default: break;
     }
