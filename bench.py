@@ -37,6 +37,8 @@ WORKLOADS = {
     "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
     # BASELINE.json configs[3]'s shape on one GPU: WN18 (V 40,943 / R 18), the 10,000 real valid+test triples as graph
     "wn18_block": ("wn18_valid_test", 40943, 18, 500, 2, "block", 100, 10000),
+    # BASELINE.json configs[4]'s space on one GPU: FB15k (V 14,951 / R 1,345), 15,000 real valid triples as graph
+    "fb15k_block": ("fb15k_minibatch", 14951, 1345, 500, 2, "block", 100, 15000),
     # BASELINE.json configs[2]: basis decomposition, B = 2 (and settings/gcn_basis.exp's own B = 5)
     "fb237_basis_b2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 15000),
     "fb237_basis_b5": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 5, 15000),
@@ -279,6 +281,36 @@ def main():
                 if extra in k:
                     roofline[extra] = k[extra]
 
+    # ---- the whole step against the chip (north_star: throughput "as achieved fraction of HBM roofline"):
+    # algorithmic bytes / flops of every kernel of one step (this rank's share) over the measured step time
+    step_roofline = None
+    if kernels:
+        P, I = 4.0 * V * d, 12.0 * E_g
+        if kind == "block":
+            sd = d // nb
+            Wl = 4.0 * (2 * R * nb * sd * sd + d * d)
+        else:
+            Wl = 4.0 * (2 * d * nb * d + 2 * R * nb + d * d)
+        compulsory = L * (2 * I + 5 * P + 3 * Wl) + 4 * P          # B_alg of one encoder step
+        staged = sum(k["alg_bytes"] * k["launches_per_step"] for k in kernels)
+        sf = sum(k["alg_flops"] * k["launches_per_step"] for k in kernels)
+        sec = ms_per_step * 1e-3
+        ceiling = compulsory / (PEAK_HBM_GBS * 1e9) + sf / (PEAK_F32_MFMA_TFS * 1e12)
+        step_roofline = {"compulsory_bytes_per_step": compulsory, "kernel_sum_bytes_per_step": staged,
+                         "alg_flops_per_step": sf,
+                         "hbm_gbs": round(compulsory / sec / 1e9, 1),
+                         "hbm_frac": round(compulsory / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         "hbm_frac_kernel_sum": round(staged / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         "fp32_tflops": round(sf / sec / 1e12, 2),
+                         "fp32_mfma_frac": round(sf / sec / 1e12 / PEAK_F32_MFMA_TFS, 4),
+                         "serial_ceiling_ms": round(ceiling * 1e3, 4),
+                         "frac_of_serial_ceiling": round(ceiling / sec, 4),
+                         "note": "whole step on this rank over the measured step time.  compulsory = SURVEY 8d's "
+                                 "L*(2I+5P+3W)+4P (each distinct input read once, each output written once); "
+                                 "kernel_sum = what the two-stage kernels move by design (messages staged through "
+                                 "HBM / L2 between the relation-major and the row-major stage); ceiling = "
+                                 "compulsory / 8 TB/s + fp32 flops / 157.3 TF with nothing overlapped"}
+
     # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
     cpu = None
     if rank == 0 and world == 1 and args.cpu_steps > 0:
@@ -298,15 +330,15 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % ("WN18" if args.workload.startswith("wn18") else "Toy" if args.workload.startswith("toy") else "FB15k-237", kind),
+            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % ({"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(args.workload[:4], "FB15k-237"), kind),
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == 0 else
                      "f32 (dense contractions: fp32 operands split exactly into 3 bf16, %d of 9 partial products on the "
                      "bf16 matrix cores, fp32 accumulation; error vs float64 equal to the fp32 MFMA's)" % args.gemm_mode,
-            "data": "real FB15k-237 valid+test graph structure (15,000-edge minibatch per SURVEY 8d), "
-                    "reference-distribution random-init weights, synthetic upstream gradient",
+            "data": "real graph structure (fixture %s of tests/golden/graphs.npz, %d edges; SURVEY 8d), "
+                    "reference-distribution random-init weights, synthetic upstream gradient" % (graph_name, E_g),
             "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
                        "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
@@ -317,7 +349,7 @@ def main():
                        "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
             "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
             "message_edges_per_s": round(2 * L * value, 1),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,
         }
         if cpu:

@@ -66,7 +66,10 @@ enum {
   RGCN_BUF_DSELF_EXCHANGE = 2, /* [d,d] partial dW_self a multi-GPU run all-reduces */
   RGCN_BUF_INDEG = 3,      /* int32 [V] in-degree inside the fed graph  */
   RGCN_BUF_OUTDEG = 4,     /* int32 [V] out-degree inside the fed graph */
-  RGCN_BUF_ROWPTR = 5      /* int32 [V+1] incidence CSR offsets (owned relations only) */
+  RGCN_BUF_ROWPTR = 5,     /* int32 [V+1] incidence CSR offsets (owned relations only) */
+  RGCN_BUF_NORM_EXCHANGE = 6,   /* float [1] squared norm of this rank's relation-sharded gradients (optimizer phases) */
+  RGCN_BUF_DBASIS_EXCHANGE = 7  /* basis kind: [2,B,d,d] partial gradient of the replicated basis tensors of the
+                                   backward layer in flight, which a multi-GPU run all-reduces */
 };
 
 /*
@@ -210,7 +213,9 @@ rgcn_status rgcn_negative_sample_device(rgcn_ctx* ctx, const int32_t* batch_dev,
  *   filtered_rank[i] = raw_rank[i] - #{e in filter_idx[filter_ptr[i] : filter_ptr[i+1]] : score[e] >= score[gold]} + 1
  * (the filter list holds the known completions of the pair, the gold entity among them).  Comparisons are made
  * on fp32 sigmoid values as in the reference (saturated scores tie).  Everything is a device pointer;
- * rgcn_rank_reserve(max_queries) sizes the [max_queries, V] score buffer, longer inputs are chunked. */
+ * rgcn_rank_reserve(max_queries) sizes the [max_queries, V] score buffer, longer inputs are chunked.
+ * Relation-sharded contexts: the codes are replicated after the forward pass, so each rank ranks its own slice
+ * of the queries (no collective) and the caller concatenates. */
 rgcn_status rgcn_rank_reserve(rgcn_ctx* ctx, int64_t max_queries);
 rgcn_status rgcn_rank_device(rgcn_ctx* ctx, const int32_t* x_dev, int64_t num_queries, int32_t predict_object,
                              const int64_t* filter_ptr_dev, const int32_t* filter_idx_dev, int32_t* raw_rank_dev,
@@ -221,9 +226,19 @@ rgcn_status rgcn_rank_device(rgcn_ctx* ctx, const int32_t* x_dev, int64_t num_qu
 rgcn_status rgcn_optimizer_config(rgcn_ctx* ctx, float learning_rate, float beta1, float beta2, float epsilon,
                                   float max_grad_norm);
 rgcn_status rgcn_optimizer_step(rgcn_ctx* ctx);
+/* The same step in two phases around its one exchange point on a relation-sharded context: the
+ * squared norm of the relation-sharded gradients (block W_forward / W_backward, basis C_forward / C_backward:
+ * owner-only, zero elsewhere) is a sum over ranks.  _norm_partial leaves this rank's share in
+ * RGCN_BUF_NORM_EXCHANGE; the caller sum-all-reduces it (rgcn_optimizer_step does, with RCCL); _apply clips by
+ * the global norm and runs Adam.  Replicated tensors receive identical updates on every rank; a relation's
+ * weights are current on its owner only, so the owner map must stay fixed over a sharded training run.  The
+ * decoder pass (rgcn_decoder_loss_backward_device) is replicated: same batch, same result on every rank. */
+rgcn_status rgcn_optimizer_norm_partial(rgcn_ctx* ctx);
+rgcn_status rgcn_optimizer_apply(rgcn_ctx* ctx);
 /* One TensorflowOptimizer.update_from_batch (optimize.py:81-88) entirely on the device, asynchronous:
  * graph prep (or adoption of a prefetched one), encoder forward (train), decoder loss + gradients,
- * encoder backward, and -- if rgcn_optimizer_config was called -- clip + Adam. */
+ * encoder backward, and -- if rgcn_optimizer_config was called -- clip + Adam.  On a sharded context (after
+ * rgcn_comm_init) the same sequence with its exchanges on RCCL; every rank passes the same graph and batch. */
 rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges,
                                    const int32_t* x_dev, const float* y_dev, int64_t num_triples,
                                    uint64_t dropout_seed, float regularization_parameter);

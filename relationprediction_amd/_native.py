@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "librgcn.so")
 ABI_VERSION = 1
 KIND_BLOCK, KIND_BASIS = 0, 1
 NORM_INTENDED, NORM_TF_AS_EXECUTED, NORM_NONE = 0, 1, 2
-BUF_EXCHANGE, BUF_SELF, BUF_DSELF_EXCHANGE, BUF_INDEG, BUF_OUTDEG, BUF_ROWPTR = range(6)
+BUF_EXCHANGE, BUF_SELF, BUF_DSELF_EXCHANGE, BUF_INDEG, BUF_OUTDEG, BUF_ROWPTR, BUF_NORM_EXCHANGE, \
+    BUF_DBASIS_EXCHANGE = range(8)
 
 KINDS = {"block": KIND_BLOCK, "basis": KIND_BASIS}
 NORMS = {"intended": NORM_INTENDED, "tf_as_executed": NORM_TF_AS_EXECUTED, "none": NORM_NONE}
@@ -80,6 +81,8 @@ _SIGS = {
     "rgcn_rank_reserve": (C.c_int32, [_P, C.c_int64]),
     "rgcn_rank_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "rgcn_optimizer_step": (C.c_int32, [_P]),
+    "rgcn_optimizer_norm_partial": (C.c_int32, [_P]),
+    "rgcn_optimizer_apply": (C.c_int32, [_P]),
     "rgcn_train_step_device": (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint64, C.c_float]),
     "rgcn_prefetch_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
     "rgcn_set_relation_owner": (C.c_int32, [_P, _P, C.c_int32]),
@@ -431,6 +434,12 @@ class Engine:
     def optimizer_step(self):
         self._check(self.lib.rgcn_optimizer_step(self.ctx))
 
+    def optimizer_norm_partial(self):
+        self._check(self.lib.rgcn_optimizer_norm_partial(self.ctx))
+
+    def optimizer_apply(self):
+        self._check(self.lib.rgcn_optimizer_apply(self.ctx))
+
     def train_step_device(self, triples_dev, num_edges, x_dev, y_dev, num_triples, seed=0, reg_param=0.01):
         self._check(self.lib.rgcn_train_step_device(self.ctx, triples_dev.ptr, int(num_edges), x_dev.ptr, y_dev.ptr,
                                                     int(num_triples), C.c_uint64(seed), C.c_float(reg_param)))
@@ -449,8 +458,10 @@ class Engine:
     def forward_layer_finish(self, l):
         self._check(self.lib.rgcn_forward_layer_finish(self.ctx, l))
 
-    def backward_begin(self, dcodes_dev):
-        self._check(self.lib.rgcn_backward_begin(self.ctx, dcodes_dev.ptr))
+    def backward_begin(self, dcodes_dev=None):
+        """dcodes_dev None: the decoder's own dL/dcodes (rgcn_dcodes_device), which never leaves the device"""
+        ptr = self.lib.rgcn_dcodes_device(self.ctx) if dcodes_dev is None else dcodes_dev.ptr
+        self._check(self.lib.rgcn_backward_begin(self.ctx, ptr))
 
     def backward_layer_partial(self, l):
         self._check(self.lib.rgcn_backward_layer_partial(self.ctx, l))
@@ -468,6 +479,10 @@ class Engine:
             out = np.empty(self.V + 1, dtype=np.int32)
         elif which == BUF_DSELF_EXCHANGE:
             out = np.empty((self.d, self.d), dtype=np.float32)
+        elif which == BUF_NORM_EXCHANGE:
+            out = np.empty(1, dtype=np.float32)
+        elif which == BUF_DBASIS_EXCHANGE:
+            out = np.empty((2, int(self.cfg.num_bases), self.d, self.d), dtype=np.float32)
         else:
             out = np.empty((self.V, self.d), dtype=np.float32)
         self._check(self.lib.rgcn_read_buffer(self.ctx, which, _ptr(out), out.nbytes))

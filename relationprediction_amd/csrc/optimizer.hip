@@ -67,10 +67,26 @@ __global__ void __launch_bounds__(kOptThreads) k_sqnorm_part(OptTable tab, float
 // state[0] = clip scale, state[1] = global norm (for inspection), state[2] = step count t, state[3] = the
 // bias-corrected rate lr * sqrt(1 - beta2^t) / (1 - beta1^t).  t advances HERE, on the device, so that a
 // captured hipGraph of the train step (rgcn_capture_*) keeps counting when it is replayed.
-__global__ void __launch_bounds__(256) k_clip_scale(const float* __restrict__ part, int nparts, float max_norm,
-                                                    float lr, float b1, float b2, float* __restrict__ state) {
+// Sum of a range of block partials, as one float: the squared norm of this rank's relation-sharded gradients,
+// which a multi-GPU run sum-all-reduces before k_clip_scale adds it to the replicated tensors' partials.
+__global__ void __launch_bounds__(256) k_sum_range(const float* __restrict__ part, int nparts, float* __restrict__ out) {
   __shared__ double red[256];
   double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+__global__ void __launch_bounds__(256) k_clip_scale(const float* __restrict__ part, int nparts,
+                                                    const float* __restrict__ exchanged, float max_norm,
+                                                    float lr, float b1, float b2, float* __restrict__ state) {
+  __shared__ double red[256];
+  double a = (exchanged && threadIdx.x == 0) ? (double)exchanged[0] : 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
   red[threadIdx.x] = a;
   __syncthreads();
@@ -110,31 +126,47 @@ __global__ void __launch_bounds__(kOptThreads) k_adam(OptTable tab, const float*
 
 }  // namespace
 
-rgcn_status optimizer_step(rgcn_ctx* c) {
+namespace {
+
+// Relation-sharded tensors: block W_forward / W_backward, basis C_forward / C_backward.  On a
+// world > 1 context each rank holds the gradient of the relations it owns (zeros elsewhere), so their squared
+// norm is a sum over ranks; everything else is replicated and identical on every rank.
+bool is_sharded_param(const rgcn_ctx* c, const Param& p) {
+  if (c->world <= 1) return false;
+  const char* pre = c->kind == RGCN_KIND_BLOCK ? "W_" : "C_";
+  return p.name.compare(0, 2, pre) == 0 && (p.name[2] == 'f' || p.name[2] == 'b') && p.name != "W_relation";
+}
+
+// the launch table: replicated tensors first (blocks [0, *nrep)), sharded ones behind them
+rgcn_status build_table(rgcn_ctx* c, OptTable& tab, int* nrep, double* total) {
   OptimizerState& o = c->opt;
-  if (!o.configured) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_optimizer_config was not called");
-  OptTable tab;
   tab.count = 0;
   int nblocks = 0;
+  *total = 0;
   if (o.m.empty()) {
     o.m.assign(c->params.size(), nullptr);
     o.v.assign(c->params.size(), nullptr);
   }
-  for (size_t i = 0; i < c->params.size(); ++i) {
-    const Param& p = c->params[i];
-    if (p.no_grad) continue;                       // the never-used layer bias: TF returns None for it
-    int64_t n = p.count;
-    if (p.name == "W_relation") n = (int64_t)c->R * c->d;     // rows >= RelationCount never get a gradient
-    if (!o.m[i]) {
-      RGCN_HIP(c, hipMalloc((void**)&o.m[i], sizeof(float) * (size_t)n));
-      RGCN_HIP(c, hipMalloc((void**)&o.v[i], sizeof(float) * (size_t)n));
-      RGCN_HIP(c, hipMemsetAsync(o.m[i], 0, sizeof(float) * (size_t)n, c->stream));
-      RGCN_HIP(c, hipMemsetAsync(o.v[i], 0, sizeof(float) * (size_t)n, c->stream));
+  for (int pass = 0; pass < 2; ++pass) {
+    for (size_t i = 0; i < c->params.size(); ++i) {
+      const Param& p = c->params[i];
+      if (p.no_grad) continue;                       // the never-used layer bias: TF returns None for it
+      if ((int)is_sharded_param(c, p) != pass) continue;
+      int64_t n = p.count;
+      if (p.name == "W_relation") n = (int64_t)c->R * c->d;     // rows >= RelationCount never get a gradient
+      if (!o.m[i]) {
+        RGCN_HIP(c, hipMalloc((void**)&o.m[i], sizeof(float) * (size_t)n));
+        RGCN_HIP(c, hipMalloc((void**)&o.v[i], sizeof(float) * (size_t)n));
+        RGCN_HIP(c, hipMemsetAsync(o.m[i], 0, sizeof(float) * (size_t)n, c->stream));
+        RGCN_HIP(c, hipMemsetAsync(o.v[i], 0, sizeof(float) * (size_t)n, c->stream));
+      }
+      if (tab.count >= kOptMaxTensors) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "too many tensors for one optimizer launch");
+      OptTensor& t = tab.t[tab.count++];
+      t.w = p.val; t.g = p.grad; t.m = o.m[i]; t.v = o.v[i]; t.n = n; t.block0 = nblocks;
+      nblocks += (int)((n + kOptThreads * kOptItems - 1) / (kOptThreads * kOptItems));
+      *total += (double)n;
     }
-    if (tab.count >= kOptMaxTensors) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "too many tensors for one optimizer launch");
-    OptTensor& t = tab.t[tab.count++];
-    t.w = p.val; t.g = p.grad; t.m = o.m[i]; t.v = o.v[i]; t.n = n; t.block0 = nblocks;
-    nblocks += (int)((n + kOptThreads * kOptItems - 1) / (kOptThreads * kOptItems));
+    if (pass == 0) *nrep = nblocks;
   }
   tab.nblocks = nblocks;
   if ((size_t)nblocks > o.part_cap) {
@@ -146,22 +178,64 @@ rgcn_status optimizer_step(rgcn_ctx* c) {
     RGCN_HIP(c, hipMalloc((void**)&o.state, 4 * sizeof(float)));
     RGCN_HIP(c, hipMemsetAsync(o.state, 0, 4 * sizeof(float), c->stream));
   }
-  o.t += 1;        // host-side mirror (exact only while no captured graph is replayed)
+  if (c->world > 1 && !o.shard_sq) {
+    RGCN_HIP(c, hipMalloc((void**)&o.shard_sq, sizeof(float)));
+    RGCN_HIP(c, hipMemsetAsync(o.shard_sq, 0, sizeof(float), c->stream));
+  }
+  return RGCN_OK;
+}
+
+}  // namespace
+
+// Phase 1: squared-norm partials of every gradient; on a sharded context the relation-sharded tensors' share
+// ends in opt.shard_sq (RGCN_BUF_NORM_EXCHANGE), which the caller sum-all-reduces before phase 2.
+rgcn_status optimizer_norm_partial(rgcn_ctx* c) {
+  OptimizerState& o = c->opt;
+  if (!o.configured) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_optimizer_config was not called");
+  OptTable tab;
+  int nrep = 0;
   double total = 0;
-  for (int i = 0; i < tab.count; ++i) total += (double)tab.t[i].n;
+  RGCN_TRY(build_table(c, tab, &nrep, &total));
   {
     ProfScope ps(c, "opt_grad_norm", 4.0 * total, 2.0 * total);
-    hipLaunchKernelGGL(k_sqnorm_part, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.part);
-    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nblocks, o.max_norm, o.lr, o.beta1,
+    hipLaunchKernelGGL(k_sqnorm_part, dim3(tab.nblocks), dim3(kOptThreads), 0, c->stream, tab, o.part);
+    if (c->world > 1)
+      hipLaunchKernelGGL(k_sum_range, dim3(1), dim3(256), 0, c->stream, o.part + nrep, tab.nblocks - nrep, o.shard_sq);
+  }
+  RGCN_HIP(c, hipGetLastError());
+  o.norm_pending = true;
+  return RGCN_OK;
+}
+
+// Phase 2: clip scale from the (exchanged) norm, then Adam on every tensor.
+rgcn_status optimizer_apply(rgcn_ctx* c) {
+  OptimizerState& o = c->opt;
+  if (!o.norm_pending) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_optimizer_apply without rgcn_optimizer_norm_partial");
+  o.norm_pending = false;
+  OptTable tab;
+  int nrep = 0;
+  double total = 0;
+  RGCN_TRY(build_table(c, tab, &nrep, &total));
+  o.t += 1;        // host-side mirror (exact only while no captured graph is replayed)
+  {
+    ProfScope ps(c, "opt_clip_scale", 4.0 * tab.nblocks, 0);
+    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nrep,
+                       c->world > 1 ? (const float*)o.shard_sq : (const float*)nullptr, o.max_norm, o.lr, o.beta1,
                        o.beta2, o.state);
   }
   {
     ProfScope ps(c, "opt_adam", 28.0 * total, 10.0 * total);
-    hipLaunchKernelGGL(k_adam, dim3(nblocks), dim3(kOptThreads), 0, c->stream, tab, o.state, o.beta1, o.beta2,
+    hipLaunchKernelGGL(k_adam, dim3(tab.nblocks), dim3(kOptThreads), 0, c->stream, tab, o.state, o.beta1, o.beta2,
                        o.eps);
   }
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
+}
+
+rgcn_status optimizer_step(rgcn_ctx* c) {
+  RGCN_TRY(optimizer_norm_partial(c));
+  if (c->world > 1) RGCN_TRY(comm_allreduce(c, c->opt.shard_sq, 1));
+  return optimizer_apply(c);
 }
 
 void optimizer_free(rgcn_ctx* c) {
@@ -170,6 +244,7 @@ void optimizer_free(rgcn_ctx* c) {
   for (float* p : o.v) if (p) (void)hipFree(p);
   if (o.part) (void)hipFree(o.part);
   if (o.state) (void)hipFree(o.state);
+  if (o.shard_sq) (void)hipFree(o.shard_sq);
   o = OptimizerState();
 }
 

@@ -798,7 +798,8 @@ rgcn_status rgcn_decoder_loss_backward_device(rgcn_ctx* c, const int32_t* X_dev,
   RGCN_NEED(c);
   if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "the decoder needs a completed rgcn_forward");
   if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
-  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device decoder on a sharded context (not built yet)");
+  // world > 1: the codes are replicated after the last layer's exchange, so every rank runs the same decoder
+  // pass on the same batch and holds identical dL/dcodes and dL/dW_relation (the kernels are deterministic)
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
   RGCN_TRY(decoder_prepare(c, X_dev, N));
   RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
@@ -839,7 +840,8 @@ rgcn_status rgcn_rank_device(rgcn_ctx* c, const int32_t* x_dev, int64_t n, int32
   if (n < 0 || (n > 0 && (!x_dev || !filter_ptr_dev || !raw_rank_dev || !filtered_rank_dev)))
     RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
   if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_rank_device needs a completed rgcn_forward (test mode on the full graph)");
-  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "ranking on a sharded context (not built yet)");
+  // world > 1: the codes are replicated after the last exchange, so ranking needs no collective -- each rank
+  // passes its own slice of the queries and the caller concatenates
   if (c->rank_max <= 0) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_rank_reserve first");
   if (n == 0) return RGCN_OK;
   return rank_compute(c, x_dev, n, predict_object ? 1 : 0, filter_ptr_dev, filter_idx_dev, raw_rank_dev, filtered_rank_dev);
@@ -857,16 +859,20 @@ rgcn_status rgcn_optimizer_config(rgcn_ctx* c, float lr, float beta1, float beta
 
 rgcn_status rgcn_optimizer_step(rgcn_ctx* c) {
   RGCN_NEED(c);
-  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device optimizer on a sharded context (not built yet)");
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive rgcn_optimizer_norm_partial / _apply yourself)");
   return optimizer_step(c);
 }
+rgcn_status rgcn_optimizer_norm_partial(rgcn_ctx* c) { RGCN_NEED(c); return optimizer_norm_partial(c); }
+rgcn_status rgcn_optimizer_apply(rgcn_ctx* c) { RGCN_NEED(c); return optimizer_apply(c); }
 
 rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, const int32_t* X_dev,
                                    const float* Y_dev, int64_t N, uint64_t seed, float reg_param) {
   RGCN_NEED(c);
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
   if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
-  if (c->world > 1) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "device train step on a sharded context (not built yet)");
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
   {   // the decoder batch's CSRs depend on X only: build them beside the encoder's forward pass
     StreamScope side(c, 1);
@@ -1055,6 +1061,15 @@ static rgcn_status buffer_of(rgcn_ctx* c, int32_t which, void** p, int64_t* byte
       if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_STATE, "no backward layer in flight");
       *p = c->layers[l].gwself; *bytes = (int64_t)c->d * c->d * 4; return RGCN_OK;
     }
+    case RGCN_BUF_DBASIS_EXCHANGE: {
+      int l = c->bwd_layer;
+      if (c->kind != RGCN_KIND_BASIS) RGCN_FAIL(c, RGCN_ERR_STATE, "basis kind only");
+      if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_STATE, "no backward layer in flight");
+      *p = c->layers[l].grel; *bytes = (int64_t)2 * c->B * c->d * c->d * 4; return RGCN_OK;
+    }
+    case RGCN_BUF_NORM_EXCHANGE:
+      if (!c->opt.shard_sq) RGCN_FAIL(c, RGCN_ERR_STATE, "no sharded-norm buffer (world == 1, or no rgcn_optimizer_norm_partial yet)");
+      *p = c->opt.shard_sq; *bytes = 4; return RGCN_OK;
     case RGCN_BUF_INDEG: *p = c->g.indeg; *bytes = (int64_t)c->V * 4; return RGCN_OK;
     case RGCN_BUF_OUTDEG: *p = c->g.outdeg; *bytes = (int64_t)c->V * 4; return RGCN_OK;
     case RGCN_BUF_ROWPTR: *p = c->g.row_ptr; *bytes = (int64_t)(c->V + 1) * 4; return RGCN_OK;
@@ -1073,7 +1088,8 @@ rgcn_status rgcn_write_buffer(rgcn_ctx* c, int32_t which, const void* host, int6
   void* p; int64_t n;
   RGCN_TRY(buffer_of(c, which, &p, &n));
   if (!host || bytes != n) RGCN_FAIL(c, RGCN_ERR_INVALID, "buffer size mismatch");
-  if (which != RGCN_BUF_EXCHANGE && which != RGCN_BUF_DSELF_EXCHANGE)
+  if (which != RGCN_BUF_EXCHANGE && which != RGCN_BUF_DSELF_EXCHANGE && which != RGCN_BUF_NORM_EXCHANGE &&
+      which != RGCN_BUF_DBASIS_EXCHANGE)
     RGCN_FAIL(c, RGCN_ERR_INVALID, "only the exchange buffers are writable");
   return to_dev(c, p, host, (size_t)n);
 }

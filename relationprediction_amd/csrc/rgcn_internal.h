@@ -191,7 +191,9 @@ struct OptimizerState {
   std::vector<float*> m, v;
   float* part = nullptr;
   size_t part_cap = 0;
-  float* state = nullptr;    // [clip scale, global norm]
+  float* state = nullptr;    // [clip scale, global norm, step count t, bias-corrected rate]
+  float* shard_sq = nullptr; // world > 1: squared norm of this rank's relation-sharded gradients (all-reduced)
+  bool norm_pending = false; // optimizer_norm_partial ran, optimizer_apply has not
 };
 
 }  // namespace rgcn
@@ -372,6 +374,8 @@ void decoder_free(rgcn_ctx* c);
 rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N);
 rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param);
 rgcn_status optimizer_step(rgcn_ctx* c);
+rgcn_status optimizer_norm_partial(rgcn_ctx* c);
+rgcn_status optimizer_apply(rgcn_ctx* c);
 // ---- ranking.hip
 rgcn_status rank_reserve(rgcn_ctx* c, int64_t max_queries);
 void rank_free(rgcn_ctx* c);

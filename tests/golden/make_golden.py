@@ -6,7 +6,8 @@ graphs.npz   real graph structure read from the reference's data files with the 
              file formats (code/common/io.py:5-39): Toy train (43 triples, complete) and the
              FB15k-237 minibatch of SURVEY.md 8d config 2 "graph A" (30,000 of the 38,001 valid+test
              triples, seed 0, no replacement; then a random 15,000 of them = GraphSplitSize 0.5); the 10,000 WN18
-             valid+test triples (config 4's entity / relation space: 40,943 / 18).
+             valid+test triples (config 4's entity / relation space: 40,943 / 18); 15,000 of the 50,000 real FB15k
+             valid triples (config 5's space: 14,951 / 1,345; seed 0, no replacement).
 expected.npz fingerprints (l2 norm, sum, 256 sampled entries) of the ORACLE's outputs on the cases
              in tests/helpers.py:GOLDEN_CASES.  The reference ships no golden vectors and TF 1.4
              cannot run here ("parity unpinned"), so these pin the oracle against regressions and
@@ -61,8 +62,13 @@ def make_graphs():
     wn = np.concatenate([read_triples(REF + "/wn18/valid.txt", ent, rel),
                          read_triples(REF + "/wn18/test.txt", ent, rel)], axis=0)
     assert wn.shape == (10000, 3) and len(ent) == 40943 and len(rel) == 18
+    ent = read_dictionary(REF + "/FB15k/entities.dict")
+    rel = read_dictionary(REF + "/FB15k/relations.dict")
+    fb15k = read_triples(REF + "/FB15k/valid.txt", ent, rel)
+    assert fb15k.shape == (50000, 3) and len(ent) == 14951 and len(rel) == 1345
+    fb15k_batch = fb15k[np.random.default_rng(0).choice(fb15k.shape[0], size=15000, replace=False)]
     np.savez_compressed(os.path.join(HERE, "graphs.npz"), toy_train=toy, fb237_minibatch=fb[split],
-                        fb237_valid_test=fb, wn18_valid_test=wn)
+                        fb237_valid_test=fb, wn18_valid_test=wn, fb15k_minibatch=fb15k_batch)
 
 
 def make_expected():

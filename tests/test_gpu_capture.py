@@ -101,3 +101,50 @@ def test_captured_train_step_matches_stepwise_training(native):
                 b.free()
         eng.close()
         ref.close()
+
+
+def test_config5_fb15k_train_step_in_a_hipgraph(native):
+    """BASELINE config 5 on one GPU: FB15k's space (V 14,951 / R 1,345), block kind d = 500, E_g = 15,000 real
+    valid triples, the DistMult decoder on N = 330,000 triples (30,000 positives + 10 corruptions each), clip and
+    Adam — the whole train step captured once and replayed; each replay must leave exactly the loss and the
+    weights that the same step issued call by call leaves."""
+    import helpers
+    V, R, d, L, nb = 14951, 1345, 500, 2, 100
+    triples = helpers.load_graph("fb15k_minibatch")
+    rng = np.random.RandomState(3)
+    others = np.stack([rng.randint(0, V, 15000), rng.randint(0, R, 15000), rng.randint(0, V, 15000)], 1)
+    X, Y = decoder_batch(rng, np.concatenate([triples, others]).astype(np.int32), V, neg_rate=10)
+    assert len(X) == 330000
+    import oracle
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=np.random.RandomState(4))
+    engines, held = [], []
+    try:
+        for _ in range(2):
+            e = native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=len(triples))
+            engines.append(e)
+            e.set_params(params)
+            e.decoder_reserve(len(X))
+            e.optimizer_config(lr=0.01, max_grad_norm=1.0)
+            held.append((e.to_device(triples), e.to_device(X), e.to_device(Y)))
+        eng, ref = engines
+        (T, Xd, Yd), (rT, rX, rY) = held
+        eng.train_step_device(T, len(triples), Xd, Yd, len(X), seed=1, reg_param=0.01)
+        ref.train_step_device(rT, len(triples), rX, rY, len(X), seed=1, reg_param=0.01)
+        eng.sync()
+        eng.capture_begin()
+        eng.train_step_device(T, len(triples), Xd, Yd, len(X), seed=20, reg_param=0.01)
+        gid = eng.capture_end()
+        for launch in (1, 2, 3):
+            eng.graph_launch(gid)
+            ref.train_step_device(rT, len(triples), rX, rY, len(X), seed=20 + launch, reg_param=0.01)
+            assert eng.loss() == ref.loss(), launch
+        assert np.isfinite(eng.loss()) and eng.loss() < 10.0
+        got, want = eng.get_params(), ref.get_params()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        for t in held:
+            for b in t:
+                b.free()
+        for e in engines:
+            e.close()

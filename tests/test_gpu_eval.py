@@ -67,6 +67,56 @@ def test_ranks_match_reference_definition(native, V, R, d, nb, E, scale):
         eng.close()
 
 
+def test_sharded_contexts_rank_their_own_query_slices(native):
+    """Evaluation on a relation-sharded encoder (SURVEY 8e + f3): two contexts on one device, the test as the
+    collective for the test-mode forward, then each rank ranks ITS half of the queries; the concatenation is what
+    the unsharded context returns for all of them."""
+    from relationprediction_amd.sharding import lpt_partition
+    V, R, d, nb, E, L, world = 150, 8, 20, 4, 700, 2, 2
+    params, triples, _, _ = make_case(V, R, d, L, "block", nb, E, seed=31)
+    queries = triples[np.random.RandomState(5).choice(E, 120, replace=False)]
+    known = known_lists(triples, True)
+    owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
+    ref = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    engs = [native.Engine(V, R, d, L, "block", nb, max_edges=E, rank=r, world=world) for r in range(world)]
+    try:
+        ref.set_params(params)
+        ref.set_graph(triples)
+        ref.forward(train=False)
+        ref.rank_reserve(64)
+        ptr, idx = csr_for(queries, known, True)
+        want_raw, want_filt = ref.ranks(queries, True, ptr, idx)
+        for e in engs:
+            e.set_params(params)
+            e.set_relation_owner(owner)
+            e.set_graph(triples)
+            e.forward_begin(train=False)
+            e.rank_reserve(64)
+        for l in range(1, L + 1):
+            for e in engs:
+                e.forward_layer_partial(l)
+            total = sum(e.read_buffer(native.BUF_EXCHANGE) for e in engs)
+            for e in engs:
+                e.write_buffer(native.BUF_EXCHANGE, total)
+                e.forward_layer_finish(l)
+        raw, filt = [], []
+        for r, e in enumerate(engs):
+            mine = queries[r::world]
+            ptr, idx = csr_for(mine, known, True)
+            a, b = e.ranks(mine, True, ptr, idx)
+            raw.append(a)
+            filt.append(b)
+        got_raw, got_filt = np.empty_like(want_raw), np.empty_like(want_filt)
+        for r in range(world):
+            got_raw[r::world], got_filt[r::world] = raw[r], filt[r]
+        # the exchanged sum and the single-context reduction add in different orders: a near-tie may move a rank by 1
+        assert np.mean(got_raw != want_raw) <= 0.02 and np.abs(got_raw - want_raw).max() <= 1
+        assert np.mean(got_filt != want_filt) <= 0.02 and np.abs(got_filt - want_filt).max() <= 1
+    finally:
+        for e in [ref] + engs:
+            e.close()
+
+
 def test_rank_argument_checks(native):
     V, R, d = 50, 3, 8
     params, triples, _, _ = make_case(V, R, d, 1, "block", 2, 60, seed=1)

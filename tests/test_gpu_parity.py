@@ -440,6 +440,35 @@ def test_wn18_shape_forward_parity(native):
         eng.close()
 
 
+def test_fb15k_shape_forward_parity(native):
+    """BASELINE config 5's entity / relation space on one GPU: FB15k (V 14,951, R 1,345 -> 27.9 MB of block
+    weights per layer, 694 non-empty relations in the graph, most with a handful of edges), 15,000 real valid
+    triples as graph, d = 500, block kind, train mode with injected masks; forward against the oracle, then
+    the layer-2 relation-weight gradients against the oracle's backward (the many-small-relations regime of the
+    relation-major kernels and their slab reduce)."""
+    V, R, d, L, nb = 14951, 1345, 500, 2, 100
+    triples = helpers.load_graph("fb15k_minibatch")
+    rng = np.random.RandomState(12)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    masks = [(rng.rand(V, d) < 0.8).astype(np.uint8) for _ in range(L)]
+    dcodes = (rng.randn(V, d) * 0.01).astype(np.float32)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, keep_prob=0.8, dropout_masks=masks)
+    eng = native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=len(triples))
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, masks=masks)
+        for l in range(L + 1):
+            assert float(np.abs(eng.activation(l) - oacts[l]).max()) <= FWD_ATOL, l
+        eng.backward(dcodes)
+        grads = eng.get_grads()
+        for k in ("W_f2", "W_b2", "W_self2"):          # above the relu gates: no gate flips to account for
+            scale = max(float(np.abs(ograds[k]).max()), 1e-6)
+            assert float(np.abs(grads[k] - ograds[k]).max()) <= 2e-4 * scale + 1e-6, k
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------ relation sharding on one GPU
 @pytest.mark.parametrize("world", [2, 4])
 def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4):

@@ -163,3 +163,94 @@ def test_device_negative_sampler_layout_and_distribution(native):
     expected = len(repl) / float(V)
     chi2 = ((counts - expected) ** 2 / expected).sum()
     assert abs(chi2 - V) < 5 * np.sqrt(2 * V), chi2
+
+
+@pytest.mark.parametrize("kind,nb,world", [("block", 4, 2), ("block", 4, 3), ("basis", 2, 2)])
+def test_sharded_train_steps_match_the_unsharded_run(native, kind, nb, world):
+    """Relation-sharded train step (SURVEY 8e + 8f f1/f2) with `world` contexts on ONE device and the test as
+    the collective (read_buffer / write_buffer at every exchange point rgcn_train_step_device puts on RCCL):
+    forward and backward exchanges per layer, replicated decoder, sharded squared-norm exchange, Adam.  After
+    several steps every rank holds the weights of the unsharded run: replicated tensors everywhere, a relation's
+    weights on its owner."""
+    from relationprediction_amd.sharding import lpt_partition
+    V, R, d, L, E = 90, 10, 20, 2, 600
+    params, triples, _, _ = make_case(V, R, d, L, kind, nb, E, seed=21)
+    X, Y = decoder_batch(np.random.RandomState(2), triples[:200], V)
+    owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
+    ref = native.Engine(V, R, d, L, kind, nb, max_edges=E)
+    engs = [native.Engine(V, R, d, L, kind, nb, max_edges=E, rank=r, world=world) for r in range(world)]
+    held = []
+
+    def exchange(which):
+        total = sum(e.read_buffer(which) for e in engs)
+        for e in engs:
+            e.write_buffer(which, total)
+
+    def same_trajectory(got, want, what):
+        # Adam's first steps move a weight by about lr * sign(g): where a gradient entry is pure cancellation
+        # noise the two summation orders may disagree on its sign, so a handful of entries may sit up to
+        # 2 * lr * steps apart; everything else must agree closely
+        diff = np.abs(got - want)
+        assert float(diff.max()) <= 2 * 0.01 * 4 + 1e-6, what
+        assert float((diff > 2e-4).mean()) <= 0.002, (what, float((diff > 2e-4).mean()))
+
+    try:
+        for e in [ref] + engs:
+            e.set_params(params)
+            e.decoder_reserve(len(X))
+            e.optimizer_config(lr=0.01, max_grad_norm=1.0)
+            held.append((e.to_device(triples), e.to_device(X), e.to_device(Y)))
+        for e in engs:
+            e.set_relation_owner(owner)
+        for step in range(4):
+            T, Xd, Yd = held[0]
+            ref.train_step_device(T, E, Xd, Yd, len(X), seed=100 + step, reg_param=0.01)
+            for e in engs:
+                e.set_graph(triples)
+                e.forward_begin(train=True, seed=100 + step)
+            for l in range(1, L + 1):
+                for e in engs:
+                    e.forward_layer_partial(l)
+                exchange(native.BUF_EXCHANGE)
+                for e in engs:
+                    e.forward_layer_finish(l)
+            for e, (_, Xd, Yd) in zip(engs, held[1:]):
+                e.decoder_loss_backward_device(Xd, Yd, len(X), 0.01)
+                e.backward_begin()                      # the decoder's own dL/dcodes
+            for l in range(L, 0, -1):
+                for e in engs:
+                    e.backward_layer_partial(l)
+                exchange(native.BUF_EXCHANGE)
+                exchange(native.BUF_DSELF_EXCHANGE)
+                if kind == "basis":
+                    exchange(native.BUF_DBASIS_EXCHANGE)
+                for e in engs:
+                    e.backward_layer_finish(l)
+            for e in engs:
+                e.backward_end()
+                e.optimizer_norm_partial()
+            exchange(native.BUF_NORM_EXCHANGE)
+            for e in engs:
+                e.optimizer_apply()
+            for e in engs:
+                assert abs(e.loss() - ref.loss()) <= 1e-5 * max(1.0, abs(ref.loss())), step
+        want = ref.get_params()
+        sharded = ("W_f", "W_b") if kind == "block" else ("C_f", "C_b")
+        for r, e in enumerate(engs):
+            got = e.get_params()
+            for k, w in want.items():
+                if k.startswith(sharded):
+                    mine = owner == r
+                    assert mine.any()
+                    same_trajectory(got[k][mine], w[mine], (r, k))
+                    assert np.array_equal(got[k][~mine], params[k][~mine]), (r, k)   # never touched off-owner
+                else:
+                    same_trajectory(got[k], w, (r, k))
+        moved = max(float(np.abs(want[k] - params[k]).max()) for k in want)
+        assert moved > 0.02                                       # four Adam steps of 0.01 did happen
+    finally:
+        for t in held:
+            for b in t:
+                b.free()
+        for e in [ref] + engs:
+            e.close()
