@@ -325,6 +325,8 @@ def main():
         med = float(np.median(ts))
         cpu = {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                "ms_per_step": round(med * 1e3, 1),
+               "threads": "BLAS threads = host cores for the dense products (self-loop, basis); the sparse incidence "
+                          "products, gathers and batched 5x5 products of the TF-shaped dataflow run on one thread",
                "sample": "%d steps of the same %s minibatch (E_g=%d) through oracle.encoder_step "
                          "(numpy/scipy fp32, TF-dataflow-shaped), median" % (args.cpu_steps, args.workload, E_g)}
 

@@ -124,6 +124,49 @@ def test_train_step_device_with_clip_and_adam(native, kind, nb):
         eng.close()
 
 
+def test_train_step_edge_shapes(native):
+    """The shapes a driver can produce at its corners, one context, back to back: an empty message graph (the
+    encoder reduces to its self-loops), a single decoder triple, a batch whose triples all hit one entity, the
+    graph at exactly max_edges, and sizes that shrink and grow between steps.  Every step: finite loss, equal to
+    the oracle's on the weights the step started from."""
+    V, R, d, L, nb, Emax = 70, 6, 20, 2, 4, 400
+    params, triples, _, _ = make_case(V, R, d, L, "block", nb, Emax, seed=9)
+    rng = np.random.RandomState(4)
+    X_all, Y_all = decoder_batch(rng, triples, V)
+    one_entity = np.stack([np.full(50, 3), rng.randint(0, R, 50), np.full(50, 3)], 1).astype(np.int32)
+    cases = [(0, X_all[:40], Y_all[:40]), (Emax, X_all[:1], Y_all[:1]), (17, one_entity, np.ones(50, np.float32)),
+             (Emax, X_all, Y_all), (1, X_all[:7], Y_all[:7]), (Emax // 2, X_all[:900], Y_all[:900])]
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=Emax)
+    bufs = []
+    try:
+        eng.set_params(params)
+        eng.decoder_reserve(len(X_all))
+        eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
+        td = eng.to_device(triples)
+        bufs.append(td)
+        for step, (E, X, Y) in enumerate(cases):
+            cur = eng.get_params()
+            xd, yd = eng.to_device(np.ascontiguousarray(X)), eng.to_device(np.ascontiguousarray(Y))
+            bufs += [xd, yd]
+            eng.train_step_device(td, E, xd, yd, len(X), seed=step, reg_param=0.01)
+            loss = eng.loss()
+            masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
+            acts = oracle.encoder_forward(cur, triples[:E], V, L, "block", mode="train", dropout_masks=masks)
+            oloss, _, _ = oracle.distmult_loss_and_grads(acts[-1], cur["W_relation"], X, Y, 0.01)
+            assert np.isfinite(loss) and abs(loss - oloss) <= 5e-5 * max(1.0, abs(oloss)), (step, loss, oloss)
+            after = eng.get_params()
+            assert all(np.isfinite(v).all() for v in after.values()), step
+            assert any(not np.array_equal(after[k], cur[k]) for k in after), step       # Adam moved something
+        with pytest.raises(native.RgcnError):
+            eng.train_step_device(td, Emax + 1, xd, yd, len(X), seed=0, reg_param=0.01)
+        with pytest.raises(native.RgcnError):
+            eng.train_step_device(td, Emax, xd, yd, len(X_all) + 1, seed=0, reg_param=0.01)
+    finally:
+        for b in bufs:
+            b.free()
+        eng.close()
+
+
 def test_device_negative_sampler_layout_and_distribution(native):
     """rgcn_negative_sample_device against the definition of NegativeSampler.transform
     (code/common/auxilliaries.py:13-33): tiling order, labels, which column may change, uniform replacements."""
