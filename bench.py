@@ -356,7 +356,8 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     tri_dev.free()
     tri_dev_b.free()
     dc_dev.free()

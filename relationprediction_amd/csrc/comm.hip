@@ -4,6 +4,8 @@
 // process (e.g. torch) already mapped a librccl.so.1, the loader hands back that same image.
 #include <dlfcn.h>
 
+#include <cstdio>
+
 #include "rgcn_internal.h"
 
 namespace rgcn {
@@ -81,6 +83,9 @@ rgcn_status comm_init(rgcn_ctx* c, const uint8_t id[128]) {
   memcpy(u.internal, id, 128);
   nccl_comm_t comm = nullptr;
   int rc = rccl().CommInitRank(&comm, c->world, u, c->rank);
+  // with NCCL_DEBUG=VERSION (set on some hosts) RCCL leaves its banner in the C stdout buffer; push it out now,
+  // so that it cannot surface after whatever the caller prints last (bench.py's one JSON line)
+  fflush(stdout);
   if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclCommInitRank", rc));
   c->comm = comm;
   return RGCN_OK;
