@@ -96,8 +96,11 @@ def main():
     params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
     dcodes = (np.random.RandomState(2).randn(V, d) * 1e-3).astype(np.float32)
 
+    # RGCN_BENCH_SHARE_GPU=1 (tests only, with RGCN_RCCL_LIBRARY pointing at the shared-memory collective of
+    # tests/collective_double): every rank on device 0, to run the multi-process path on a one-GPU box
+    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" else local_rank
     eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
-                         device=local_rank, rank=rank, world=world)
+                         device=device, rank=rank, world=world)
     eng.set_params(params)
     rdv_path = None
     if world > 1:
@@ -108,19 +111,8 @@ def main():
         owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
         eng.set_relation_owner(owner)
         rdv_path = "/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-        if rank == 0:
-            uid = _native.Engine.comm_unique_id()
-            with open(rdv_path + ".tmp", "wb") as f:
-                f.write(uid)
-            os.replace(rdv_path + ".tmp", rdv_path)
-        else:
-            deadline = time.time() + 300
-            while not os.path.exists(rdv_path):
-                if time.time() > deadline:
-                    sys.exit("rank %d: timed out waiting for the RCCL id file %s" % (rank, rdv_path))
-                time.sleep(0.05)
-            with open(rdv_path, "rb") as f:
-                uid = f.read()
+        from relationprediction_amd.sharding import share_unique_id
+        uid = share_unique_id(rank, rdv_path, _native.Engine.comm_unique_id)
         eng.comm_init(uid)
     comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
 

@@ -122,5 +122,27 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_test_collective(force=False):
+    """tests/collective_double/shm_collective.hip -> its _build/libshmcollective.so: the shared-memory stand-in
+    for librccl that tests/test_gpu_multiprocess.py binds through RGCN_RCCL_LIBRARY (test infrastructure; host
+    code only, compiled here so that the prebuilt .so travels to the GPU box with the tree)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "collective_double", "shm_collective.hip")
+    outdir = os.path.join(root, "tests", "collective_double", "_build")
+    out = os.path.join(outdir, "libshmcollective.so")
+    stamp = out + ".sha"
+    dig = _digest([src])
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
+    os.makedirs(outdir, exist_ok=True)
+    r = subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out,
+                        "-lrt"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

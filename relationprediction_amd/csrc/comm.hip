@@ -35,10 +35,19 @@ Rccl& rccl() {
 bool load_rccl(std::string* err) {
   Rccl& r = rccl();
   if (r.handle) return true;
+  // RGCN_RCCL_LIBRARY names another library with the same five entry points (the multi-process tests use it to
+  // put several ranks on one GPU, which RCCL refuses); it is bound privately, never ahead of a real RCCL
+  if (const char* over = getenv("RGCN_RCCL_LIBRARY")) {
+    r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    if (!r.handle) {
+      *err = std::string("cannot dlopen RGCN_RCCL_LIBRARY=") + over + ": " + dlerror();
+      return false;
+    }
+  }
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
-    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (r.handle) break;
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!r.handle) {
     *err = std::string("cannot dlopen librccl.so.1: ") + dlerror();

@@ -39,3 +39,24 @@ def shard_imbalance(relation_counts, owner, world):
     counts = np.asarray(relation_counts, dtype=np.float64)
     load = np.bincount(owner, weights=counts, minlength=world)
     return float(load.max() / max(load.mean(), 1e-12))
+
+
+def share_unique_id(rank, path, make_id, timeout=300.0):
+    """Hand rank 0's 128-byte communicator id to the other ranks of this node through a file (single-node
+    contract): rank 0 calls `make_id()` and publishes it atomically at `path`, the others wait for the file.
+    No process group, no torch: the launcher only has to provide RANK / WORLD_SIZE and a path every rank agrees on."""
+    import os
+    import time
+    if rank == 0:
+        uid = make_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+        return uid
+    deadline = time.time() + timeout
+    while not os.path.exists(path):
+        if time.time() > deadline:
+            raise TimeoutError("rank %d: no communicator id at %s after %.0f s" % (rank, path, timeout))
+        time.sleep(0.05)
+    with open(path, "rb") as f:
+        return f.read()

@@ -1,0 +1,52 @@
+"""The multi-process paths on the one-GPU test box: several ranks as separate processes on ONE device, with the
+shared-memory stand-in of tests/collective_double bound in place of librccl (RGCN_RCCL_LIBRARY; RCCL itself
+refuses two ranks on one GPU).  Covers what the in-process phase-API tests cannot: the library's own
+comm_allreduce call sites (rgcn_step_device / rgcn_train_step_device on world > 1 contexts) and bench.py's whole
+--gpus N control flow under the torch.distributed.run launcher."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOUBLE = os.path.join(ROOT, "tests", "collective_double")
+
+
+@pytest.fixture(scope="module")
+def collective():
+    from relationprediction_amd import build
+    return build.build_test_collective()
+
+
+def launch(nproc, port, script_args, collective, extra_env=None, timeout=240):
+    env = dict(os.environ)
+    env["RGCN_RCCL_LIBRARY"] = collective
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world,kind,nb", [(2, "block", 8), (3, "block", 8), (2, "basis", 2)])
+def test_sharded_steps_across_processes(collective, world, kind, nb):
+    r = launch(world, 29600 + world + (10 if kind == "basis" else 0),
+               [os.path.join(DOUBLE, "sharded_worker.py"), kind, str(nb)], collective)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "elastic" not in l and "torch/distributed" not in l)[-4000:]
+    assert "SHARDED-OK world=%d kind=%s" % (world, kind) in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_prints_one_json_line_last(collective, world):
+    r = launch(world, 29650 + world, ["bench.py", "--gpus", str(world), "--steps", "4", "--warmup", "1",
+                                      "--cpu-steps", "0"], collective, {"RGCN_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "elastic" not in l and "torch/distributed" not in l)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])                                  # the JSON line is the LAST line on stdout
+    assert sum(1 for l in lines if l.startswith("{")) == 1
+    assert out["n_gpus"] == world and out["steps"] == 4 and out["value"] > 0
+    assert out["config"]["parallelism"].startswith("relation-sharded x%d" % world)
+    assert out["roofline"] and any(k["kernel"] == "rccl_allreduce" for k in out["kernels"])
