@@ -259,3 +259,42 @@ def test_background_batch_producers_are_reproducible(tmp_path):
     first = runs[0]
     assert first[0][0].shape == (600, 3) and (first[0][1][:200] == 1).all()
     assert any((first[0][0] != first[k][0]).any() for k in range(1, 12))      # batches differ from one another
+
+
+def test_minibatch_transform_semantics():
+    """SURVEY 9 H8 / H9 (reference train.py:227-245): the message graph is an EXACT-k random subset of the sampled
+    batch (k = int(GraphSplitSize * batch), host side, without replacement); the decoder's positives are ALL
+    batch triples, the dropped ones included; negatives follow in NegativeSampleRate blocks with label 0.
+    Without GraphBatchSize the batch is the whole training set (H7: how the Toy configuration has to run)."""
+    from relationprediction_amd import train
+
+    class GraphEncoder(object):
+        def needs_graph(self):
+            return True
+
+    rng = np.random.RandomState(1)
+    V, R, n = 60, 4, 500
+    triples = np.unique(np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1), axis=0)
+    triples = triples.astype(np.int32)
+    as_set = {tuple(t) for t in triples}
+    for batch_size in (120, None):
+        general = {'NegativeSampleRate': '3', 'EntityCount': V, 'GraphSplitSize': '0.5'}
+        if batch_size:
+            general['GraphBatchSize'] = str(batch_size)
+        t_func = train.make_transform(triples, general, GraphEncoder())
+        graph_split, X, Y = t_func.seeded(triples, 7)
+        nb = batch_size or len(triples)
+        assert graph_split.shape == (int(0.5 * nb), 3)                       # exact-k
+        split_set = {tuple(t) for t in graph_split}
+        assert len(split_set) == len(graph_split) and split_set <= as_set    # without replacement, real edges
+        assert X.shape == (nb * 4, 3) and Y.shape == (nb * 4,)
+        positives = {tuple(t) for t in X[:nb]}
+        assert (Y[:nb] == 1).all() and (Y[nb:] == 0).all()
+        assert len(positives) == nb and split_set <= positives               # H9: dropped edges stay positives
+        assert len(positives - split_set) == nb - len(graph_split)
+        neg = X[nb:].reshape(3, nb, 3)
+        for block in neg:                                                    # each block corrupts one end of each positive
+            same_s, same_o = block[:, 0] == X[:nb, 0], block[:, 2] == X[:nb, 2]
+            assert (block[:, 1] == X[:nb, 1]).all() and (same_s | same_o).all()
+        again = t_func.seeded(triples, 7)
+        assert np.array_equal(again[0], graph_split) and np.array_equal(again[1], X)

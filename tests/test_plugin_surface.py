@@ -126,6 +126,9 @@ def test_out_of_scope_variants_fail_loudly(tmp_path):
         s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace(key + "=No", key + "=Yes"))
         with pytest.raises(NotImplementedError):
             model_builder.build_encoder(enc, np.zeros((3, 3), dtype=int))
+    s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace("SkipConnections=None", "SkipConnections=Residual"))
+    with pytest.raises(NotImplementedError):           # the reference's Residual branch is dead code
+        model_builder.build_encoder(enc, np.zeros((3, 3), dtype=int))
     s, enc, dec = load_settings(tmp_path, BLOCK_EXP.replace("Name=gcn_basis", "Name=embedding"))
     with pytest.raises(NotImplementedError):
         model_builder.build_encoder(enc, np.zeros((3, 3), dtype=int))
