@@ -298,6 +298,14 @@ rgcn_status rgcn_write_buffer(rgcn_ctx* ctx, int32_t which, const void* host, in
 rgcn_status rgcn_device_alloc(rgcn_ctx* ctx, int64_t bytes, void** dev);
 rgcn_status rgcn_device_free(rgcn_ctx* ctx, void* dev);
 rgcn_status rgcn_copy_to_device(rgcn_ctx* ctx, void* dev, const void* host, int64_t bytes);
+/* As rgcn_copy_to_device, but the host does not wait for the transfer: the data is copied to a pinned staging
+ * slot during the call (the caller's memory is free again on return) and the transfer is ordered on the
+ * context's main stream, or -- on_prefetch_stream != 0 -- on the stream rgcn_prefetch_graph_device works on, so
+ * that "upload the next minibatch's triples, then prepare its graph" runs beside the current step (the training
+ * driver's double-buffered feed; the reference re-feeds numpy arrays through feed_dict on every session.run,
+ * optimize.py:81-88).  Transfers above 1 MB fall back to waiting. */
+rgcn_status rgcn_copy_to_device_async(rgcn_ctx* ctx, void* dev, const void* host, int64_t bytes,
+                                      int32_t on_prefetch_stream);
 rgcn_status rgcn_copy_to_host(rgcn_ctx* ctx, void* host, const void* dev, int64_t bytes);
 /* HIP-event stopwatch on the context's stream (torch.cuda.Event cannot see this stream). */
 rgcn_status rgcn_timer_start(rgcn_ctx* ctx);

@@ -101,6 +101,7 @@ _SIGS = {
     "rgcn_device_alloc": (C.c_int32, [_P, C.c_int64, C.POINTER(_P)]),
     "rgcn_device_free": (C.c_int32, [_P, _P]),
     "rgcn_copy_to_device": (C.c_int32, [_P, _P, _P, C.c_int64]),
+    "rgcn_copy_to_device_async": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int32]),
     "rgcn_copy_to_host": (C.c_int32, [_P, _P, _P, C.c_int64]),
     "rgcn_timer_start": (C.c_int32, [_P]),
     "rgcn_timer_stop": (C.c_int32, [_P, C.POINTER(C.c_float)]),
@@ -518,6 +519,14 @@ class Engine:
         arr = np.ascontiguousarray(arr)
         assert arr.nbytes <= buf.nbytes
         self._check(self.lib.rgcn_copy_to_device(self.ctx, buf.ptr, _ptr(arr), arr.nbytes))
+
+    def copy_to_device_async(self, buf, arr, on_prefetch_stream=False):
+        """As copy_to_device without waiting for the transfer (rgcn_copy_to_device_async): staged through pinned
+        memory, ordered on the main stream or on the prefetch stream."""
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= buf.nbytes
+        self._check(self.lib.rgcn_copy_to_device_async(self.ctx, buf.ptr, _ptr(arr), arr.nbytes,
+                                                       1 if on_prefetch_stream else 0))
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -19,6 +19,13 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+// rocprim's default picks a block sort + ~20 merge launches below 1M items: at N = 330,000 that is 45 launches of
+// 5-7 us for the two sorts, launch-bound (0.30 ms).  With 8- to 14-bit keys the onesweep radix path is 12 launches
+// (0.19 ms).  Merge only below 4096 items.  (The encoder's 30,000-item sorts stay on the default: there onesweep's
+// 25 us passes lose to six short merge launches, and its spinning look-back blocks disturb the forward pass.)
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 4096>;
+
 namespace rgcn {
 
 namespace {
@@ -516,9 +523,9 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.slab, (size_t)q.max_chunks * d));
   size_t t1 = 0, t2 = 0;
   if (N > 0) {
-    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, q.keyv, q.keyv_s, q.valv, q.permv, 2 * N, 0,
+    RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, q.keyv, q.keyv_s, q.valv, q.permv, 2 * N, 0,
                                           bits_for((uint32_t)c->V), c->stream));
-    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, q.keyr, q.keyr_s, q.valr, q.permr, N, 0,
+    RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, t2, q.keyr, q.keyr_s, q.valr, q.permr, N, 0,
                                           bits_for((uint32_t)c->R), c->stream));
   }
   q.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
@@ -558,13 +565,13 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
     {
       ProfScope ps(c, "dec_sort_entity", 32.0 * N, 0);
       size_t tb = q.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(q.sort_tmp, tb, q.keyv, q.keyv_s, q.valv, q.permv, (size_t)2 * N, 0,
+      RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(q.sort_tmp, tb, q.keyv, q.keyv_s, q.valv, q.permv, (size_t)2 * N, 0,
                                             bits_for((uint32_t)V), c->stream));
     }
     {
       ProfScope ps(c, "dec_sort_relation", 16.0 * N, 0);
       size_t tb = q.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(q.sort_tmp, tb, q.keyr, q.keyr_s, q.valr, q.permr, (size_t)N, 0,
+      RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(q.sort_tmp, tb, q.keyr, q.keyr_s, q.valr, q.permr, (size_t)N, 0,
                                             bits_for((uint32_t)R), c->stream));
     }
   }
@@ -629,6 +636,9 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     else hipLaunchKernelGGL((k_dec_long_finish<1>), dim3(128), dim3(256), 0, c->stream, a);
   }
   {
+    // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
+    // beside the entity gradient and the encoder's backward pass (the caller joins it: stream_join(c, 2))
+    StreamScope side(c, 2);
     ProfScope ps(c, "dec_relation_grad", 8.0 * N * d + 8.0 * R * d, 3.0 * N * d);
     if (vec4)
       hipLaunchKernelGGL((k_dec_rel_partial<4>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,

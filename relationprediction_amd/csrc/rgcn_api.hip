@@ -61,7 +61,7 @@ rgcn_status stream_join(rgcn_ctx* c, int k) {
 static rgcn_status sync_all(rgcn_ctx* c) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < kAuxStreams; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipStreamSynchronize(c->main_stream));
   return RGCN_OK;
@@ -134,7 +134,7 @@ static rgcn_status check_dev_flag(rgcn_ctx* c) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   int32_t flag = 0;
   if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < kAuxStreams; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipMemcpyAsync(&flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
@@ -163,7 +163,7 @@ static void free_all(rgcn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < kAuxStreams; ++k)
     if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
   if (c->main_stream) (void)hipStreamSynchronize(c->main_stream);
   comm_destroy(c);
@@ -185,8 +185,8 @@ static void free_all(rgcn_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
-  for (int k = 0; k < 2; ++k) {
-    if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+  for (int k = 0; k < kAuxStreams; ++k) {
+    if (k < 2 && c->aux[k]) (void)hipStreamDestroy(c->aux[k]);     // aux[2] is the prefetch stream, destroyed below
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -194,6 +194,10 @@ static void free_all(rgcn_ctx* c) {
   for (hipGraphExec_t g : c->graphs) if (g) (void)hipGraphExecDestroy(g);
   for (hipGraph_t g : c->graph_defs) if (g) (void)hipGraphDestroy(g);
   if (c->replay_counter) (void)hipFree(c->replay_counter);
+  if (c->stage_host) {
+    (void)hipHostFree(c->stage_host);
+    for (hipEvent_t e : c->stage_done) if (e) (void)hipEventDestroy(e);
+  }
   if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
   if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
   delete c;
@@ -246,10 +250,18 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     RGCN_HIP(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     const char* e = getenv("RGCN_STREAM_PRIO");
     const bool use_prio = !(e && atoi(e) == 0);
-    for (int k = 0; k < 2; ++k) {
+    // Two high-priority side streams; "side stream 2" is the prefetch stream (created here, normal or low priority):
+    // both of its jobs -- the next minibatch's graph prep and the decoder's relation gradient -- are fillers.  A
+    // fifth HIP stream would share a hardware queue with one of the other four (ROCm maps streams onto 4 queues by
+    // default) and serialise against it: measured, the pipelined encoder step went from 0.60 to 0.97 ms.
+    for (int k = 0; k < 2; ++k)
       RGCN_HIP(c, hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, use_prio ? prio_hi : prio_lo));
+    const char* pp = getenv("RGCN_PF_PRIO");
+    const bool pf_low = !(pp && atoi(pp) == 1);
+    RGCN_HIP(c, hipStreamCreateWithPriority(&c->pf_stream, hipStreamNonBlocking, pf_low ? prio_lo : 0));
+    c->aux[2] = c->pf_stream;
+    for (int k = 0; k < kAuxStreams; ++k)
       RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
-    }
   }
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, hipEventDisableTiming));
@@ -344,7 +356,6 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   std::swap(c->g, c->g_alt);
   RGCN_TRY(graph_alloc(c, &c->g_alt));
   std::swap(c->g, c->g_alt);
-  RGCN_HIP(c, hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
   {
     std::vector<int32_t> owner(c->R);
     for (int r = 0; r < c->R; ++r) owner[r] = r % c->world;
@@ -803,6 +814,7 @@ rgcn_status rgcn_decoder_loss_backward_device(rgcn_ctx* c, const int32_t* X_dev,
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
   RGCN_TRY(decoder_prepare(c, X_dev, N));
   RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
+  RGCN_TRY(stream_join(c, 2));      // the relation gradient ran on its own side stream
   c->dec.loss_valid = true;
   return RGCN_OK;
 }
@@ -874,16 +886,25 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t 
   if (c->world > 1 && !c->comm)
     RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
-  {   // the decoder batch's CSRs depend on X only: build them beside the encoder's forward pass
-    StreamScope side(c, 1);
-    RGCN_TRY(decoder_prepare(c, X_dev, N));
-  }
   RGCN_TRY(step_begin(c, tri_dev, E));
   RGCN_TRY(forward_all(c, 1, seed, nullptr));
+  // The decoder batch's CSRs depend on X only.  They are built on side stream 1, forked at the START of the step,
+  // but enqueued AFTER the encoder's prep and forward: their two sorts are ~45 launches of a few microseconds, and
+  // queued first they kept the host from feeding the main stream for the first 0.3 ms of every step.
+  if (c->use_aux) {
+    RGCN_HIP(c, hipStreamWaitEvent(c->aux[1], c->ev_step_begin, 0));
+    c->stream = c->aux[1];
+    const rgcn_status ps = decoder_prepare(c, X_dev, N);
+    c->stream = c->main_stream;
+    RGCN_TRY(ps);
+  } else {
+    RGCN_TRY(decoder_prepare(c, X_dev, N));
+  }
   RGCN_TRY(stream_join(c, 1));
   RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
   c->dec.loss_valid = true;
   RGCN_TRY(backward_all(c, c->dcodes_own));
+  RGCN_TRY(stream_join(c, 2));      // dL/dW_relation, computed beside the backward pass
   RGCN_TRY(step_end(c));
   if (c->opt.configured) RGCN_TRY(optimizer_step(c));
   return RGCN_OK;
@@ -963,7 +984,7 @@ rgcn_status rgcn_capture_end(rgcn_ctx* c, int32_t* graph_id) {
   // events last recorded inside the capture are unusable outside it: give them a fresh, ordinary record
   (void)hipEventRecord(c->ev_fork, c->main_stream);
   (void)hipEventRecord(c->ev_step_begin, c->main_stream);
-  for (int k = 0; k < 2; ++k) if (c->aux[k]) (void)hipEventRecord(c->ev_join[k], c->aux[k]);
+  for (int k = 0; k < kAuxStreams; ++k) if (c->aux[k]) (void)hipEventRecord(c->ev_join[k], c->aux[k]);
   for (rgcn::GraphBufs* g : {&c->g, &c->g_alt}) {
     if (g->ev_ready) (void)hipEventRecord(g->ev_ready, c->pf_stream);
     if (g->ev_free) (void)hipEventRecord(g->ev_free, c->main_stream);
@@ -1111,6 +1132,32 @@ rgcn_status rgcn_copy_to_device(rgcn_ctx* c, void* dev, const void* host, int64_
   RGCN_NEED(c);
   if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
   return to_dev(c, dev, host, (size_t)bytes);
+}
+rgcn_status rgcn_copy_to_device_async(rgcn_ctx* c, void* dev, const void* host, int64_t bytes,
+                                      int32_t on_prefetch_stream) {
+  RGCN_NEED(c);
+  if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
+  if (bytes == 0) return RGCN_OK;
+  hipStream_t st = on_prefetch_stream ? c->pf_stream : c->main_stream;
+  if ((size_t)bytes > rgcn_ctx::kStageBytes) {      // too large for a staging slot: ordered on `st`, host waits
+    RGCN_HIP(c, hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, st));
+    RGCN_HIP(c, hipStreamSynchronize(st));
+    return RGCN_OK;
+  }
+  if (!c->stage_host) {
+    RGCN_HIP(c, hipHostMalloc((void**)&c->stage_host, rgcn_ctx::kStageSlots * rgcn_ctx::kStageBytes, hipHostMallocDefault));
+    for (int k = 0; k < rgcn_ctx::kStageSlots; ++k)
+      RGCN_HIP(c, hipEventCreateWithFlags(&c->stage_done[k], hipEventDisableTiming));
+  }
+  const int slot = c->stage_next;
+  c->stage_next = (slot + 1) % rgcn_ctx::kStageSlots;
+  RGCN_HIP(c, hipEventSynchronize(c->stage_done[slot]));      // the transfer that last used this slot has run
+  uint8_t* stage = c->stage_host + (size_t)slot * rgcn_ctx::kStageBytes;
+  memcpy(stage, host, (size_t)bytes);
+  RGCN_HIP(c, hipMemcpyAsync(dev, stage, (size_t)bytes, hipMemcpyHostToDevice, st));
+  RGCN_HIP(c, hipEventRecord(c->stage_done[slot], st));
+  return RGCN_OK;
 }
 rgcn_status rgcn_copy_to_host(rgcn_ctx* c, void* host, const void* dev, int64_t bytes) {
   RGCN_NEED(c);

@@ -60,6 +60,7 @@ constexpr int kLongRow = 32;
 // Full-graph scale only (more than 65536 messages, block kind): a row with more than kGiantRow slots is cut into
 // kGiantRow-slot pieces that separate workgroups sum; a finishing pass adds a row's pieces in piece order.
 constexpr int kGiantRow = 2048;
+constexpr int kAuxStreams = 3;
 
 struct DropSpec {
   int32_t mode;         // DropMode
@@ -205,8 +206,9 @@ struct rgcn_ctx {
   int row_lo = 0, row_hi = 0;   // self-loop row shard of this rank
   hipStream_t stream = nullptr;           // stream launches go to (main stream unless a StreamScope is active)
   hipStream_t main_stream = nullptr;
-  hipStream_t aux[2] = {nullptr, nullptr};  // side streams for independent kernels of one layer
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t aux[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};  // side streams: 0, 1 for independent kernels of one layer,
+                                                               // 2 for the decoder's relation gradient (runs beside the backward pass)
+  hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
   std::string err;
 
@@ -239,6 +241,13 @@ struct rgcn_ctx {
   rgcn::GraphBufs g;                     // ACTIVE graph structures
   rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
   hipStream_t pf_stream = nullptr;       // stream of rgcn_prefetch_graph_device
+  // pinned staging ring of rgcn_copy_to_device_async: the caller's memory is copied here during the call, the
+  // transfer itself is stream-ordered and the host does not wait for it
+  static constexpr int kStageSlots = 8;
+  static constexpr size_t kStageBytes = (size_t)1 << 20;
+  uint8_t* stage_host = nullptr;         // kStageSlots * kStageBytes, hipHostMalloc
+  hipEvent_t stage_done[kStageSlots] = {};
+  int stage_next = 0;
   bool chunk_fixed = false;              // RGCN_CHUNK in the environment pins the chunk size
   int chunk = 48;                        // messages per relation chunk (capacity-scaled upper bound; GraphBufs::chunk is per graph)
   int gemm_mode = 0;                     // 0: fp32 MFMA; 3/6/9: bf16 split with that many partial products

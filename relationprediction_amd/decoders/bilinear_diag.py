@@ -84,6 +84,10 @@ class BilinearDiag(Model):
         self.next_component.get_runtime().train_step_device_negatives(graph_edges, batch, rate,
                                                                       self.regularization_parameter, seed)
 
+    def device_stage(self, graph_edges, batch=None):
+        """feed the next train step beside the running one (runtime.stage)"""
+        self.next_component.get_runtime().stage(graph_edges, batch)
+
     def device_loss(self):
         return self.next_component.get_runtime().loss()
 

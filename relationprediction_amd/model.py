@@ -185,6 +185,9 @@ class Model(object):
     def device_train_step_negatives(self, *args):
         return self.__delegate__('device_train_step_negatives', *args)
 
+    def device_stage(self, *args):
+        return self.__delegate__('device_stage', *args)
+
     def device_loss(self):
         return self.__delegate__('device_loss')
 

@@ -270,6 +270,16 @@ class HipOptimizer(object):
         graph_edges, x, y = processed_batch
         self.model.device_train_step(graph_edges, x, y, seed)
 
+    def stage(self, processed_batch):
+        """Hand the NEXT batch's triples to the device while the step just enqueued runs (runtime.stage)."""
+        stage = getattr(self.model, 'device_stage', None)
+        if stage is None:
+            return
+        if isinstance(processed_batch, DeviceNegatives):
+            stage(processed_batch.graph_edges, processed_batch.batch)
+        else:
+            stage(processed_batch[0], None)
+
     def _sample_transformer(self):
         """The SampleTransformer if it sits directly on the data source (the only place the reference puts it
         when no Minibatches component is configured)."""
@@ -330,6 +340,8 @@ class HipOptimizer(object):
             self.update_from_batch(processed, seed=int(np.random.randint(0, 2 ** 31 - 1)))
             # host work of the next iteration (or the wait for a background-built batch) while the device runs
             processed = next(batches, None)
+            if processed is not None:
+                self.stage(processed)                        # upload + graph prep of the next step, beside this one
             train_loss = self.model.device_loss()            # synchronises with the step
             if self.stack.postprocess(train_loss) == 'stop':
                 print("Stopping training.")

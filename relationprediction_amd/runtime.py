@@ -98,6 +98,43 @@ class EncoderRuntime(object):
             self.engine.copy_to_device(buf, arr)
         return buf
 
+    def _buffer(self, name, nbytes):
+        buf = self._dev.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = _native.DeviceBuffer(self.engine, max(nbytes, 16))
+            self._dev[name] = buf
+        return buf
+
+    def stage(self, graph_edges, batch=None):
+        """Feed the NEXT train step while the current one runs: its triples go to the inactive one of two device
+        buffer pairs without the host waiting (pinned staging), the message graph on the prefetch stream where
+        rgcn_prefetch_graph_device then builds its structures beside the running step, the decoder batch (if the
+        negatives are drawn on the device) on the main stream behind that step.  The step that is then asked to
+        train on these very arrays (identity) finds everything in place."""
+        g = np.ascontiguousarray(graph_edges, dtype=np.int32).reshape(-1, 3)
+        if len(g) > self.engine.max_edges:
+            return                                   # the step itself reports the error
+        slot = getattr(self, "_slot", 0) ^ 1
+        gd = self._buffer("graph%d" % slot, g.nbytes)
+        self.engine.copy_to_device_async(gd, g, on_prefetch_stream=True)
+        self.engine.prefetch_graph_device(gd, len(g))
+        bd, nb = None, 0
+        if batch is not None:
+            b = np.ascontiguousarray(batch, dtype=np.int32).reshape(-1, 3)
+            bd, nb = self._buffer("batch%d" % slot, b.nbytes), len(b)
+            self.engine.copy_to_device_async(bd, b)
+        self._staged = (graph_edges, batch, slot, gd, len(g), bd, nb)
+
+    def _take_staged(self, graph_edges, batch):
+        st = getattr(self, "_staged", None)
+        self._staged = None
+        if st is not None and st[0] is graph_edges and st[1] is batch:
+            self._slot = st[2]
+            return st
+        return None
+
     def configure_optimizer(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8, max_grad_norm=0.0):
         self.engine.optimizer_config(learning_rate, beta1, beta2, epsilon, max_grad_norm)
 
@@ -115,7 +152,9 @@ class EncoderRuntime(object):
         if len(x) > self._dec_reserved:
             self.engine.decoder_reserve(len(x))
             self._dec_reserved = len(x)
-        gd, xd, yd = self._upload("graph", g), self._upload("X", x), self._upload("Y", y)
+        st = self._take_staged(graph_edges, None)
+        gd = st[3] if st is not None else self._upload("graph", g)
+        xd, yd = self._upload("X", x), self._upload("Y", y)
         self.engine.train_step_device(gd, len(g), xd, yd, len(x), seed=seed, reg_param=reg_param)
         self._state = None            # activations now belong to this train step's graph
         self._graph_version = None
@@ -135,7 +174,11 @@ class EncoderRuntime(object):
         if n > self._dec_reserved:
             self.engine.decoder_reserve(n)
             self._dec_reserved = n
-        gd, bd = self._upload("graph", g), self._upload("batch", b)
+        st = self._take_staged(graph_edges, batch)
+        if st is not None:
+            gd, bd = st[3], st[5]
+        else:
+            gd, bd = self._upload("graph", g), self._upload("batch", b)
         for name, nbytes in (("X", 12 * n), ("Y", 4 * n)):
             buf = self._dev.get(name)
             if buf is None or buf.nbytes < nbytes:

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Device train steps at FB15k-237 gcn_block size on fixed device-resident inputs (no host work between steps),
+for a rocprofv3 --kernel-trace timeline of rgcn_train_step_device:
+    rocprofv3 --kernel-trace -d out -o trace -- python tools/train_step_trace.py [steps]
+and tools/train_step_timeline.py out/...kernel_trace.csv prints one steady-state step."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from relationprediction_amd import _native  # noqa: E402
+from relationprediction_amd.common.shared_functions import init_encoder_params  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+V, R, d, L, nb, E = 14541, 237, 500, 2, 100, 15000
+with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
+    triples = np.ascontiguousarray(z["fb237_minibatch"].astype(np.int32))
+    pool = z["fb237_valid_test"].astype(np.int32)
+rng = np.random.RandomState(0)
+batch = np.concatenate([triples, pool[rng.choice(len(pool), 15000, replace=False)]])
+neg = np.tile(batch, (10, 1))
+side = rng.rand(len(neg)) < 0.5
+rnd = rng.randint(0, V, len(neg))
+neg[side, 2] = rnd[side]
+neg[~side, 0] = rnd[~side]
+X = np.ascontiguousarray(np.concatenate([batch, neg]).astype(np.int32))
+Y = np.concatenate([np.ones(len(batch)), np.zeros(len(neg))]).astype(np.float32)
+params = init_encoder_params(V, R, d, L, "block", nb, rng=np.random.RandomState(1))
+params["W_relation"] = np.random.RandomState(2).randn(V, d).astype(np.float32)
+eng = _native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E)
+eng.set_params(params)
+eng.decoder_reserve(len(X))
+eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
+T, Xd, Yd = eng.to_device(triples), eng.to_device(X), eng.to_device(Y)
+for i in range(steps):
+    eng.train_step_device(T, E, Xd, Yd, len(X), seed=i, reg_param=0.01)
+eng.sync()
+eng.timer_start()
+for i in range(steps):
+    eng.train_step_device(T, E, Xd, Yd, len(X), seed=100 + i, reg_param=0.01)
+ms = eng.timer_stop()
+print("train step: %.3f ms (N = %d, E_g = %d), loss %.4f" % (ms / steps, len(X), E, eng.loss()))
+for b in (T, Xd, Yd):
+    b.free()
+eng.close()
