@@ -9,7 +9,10 @@ ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", r.g
        r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("rgcn::", "")
        .replace("rocprim::ROCPRIM_400200_NS::detail::", "rocprim ").split("(")[0][:70]) for r in rows]
 ks.sort()
-adam = [i for i, k in enumerate(ks) if "k_adam" in k[3]]
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_adam"       # last kernel of a step
+adam = [i for i, k in enumerate(ks) if marker in k[3]]
+if len(sys.argv) > 3:                                          # an earlier step (1 = last, 2 = the one before ...)
+    adam = adam[:len(adam) - int(sys.argv[3]) + 1]
 lo, hi = adam[-2] + 1, adam[-1] + 1
 step = ks[lo:hi]
 t0 = ks[adam[-2]][1]
