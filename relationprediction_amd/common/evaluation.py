@@ -28,18 +28,45 @@ class MrrSummary(object):
             if vertex_freqs is not None:
                 self.results[name][self.freq_string()] = list(zip(1.0 / ranks, vertex_freqs, relation_freqs))
             if in_degrees is not None:
-                self.results[name][self.degree_string()] = self.get_degree_scores(ranks, in_degrees, out_degrees)
+                self.results[name][self.degree_string()] = self.get_individual_degree_scores(ranks, in_degrees,
+                                                                                             out_degrees)
+
+    @staticmethod
+    def get_individual_degree_scores(ranks, in_degrees, out_degrees):
+        """What results['Degree'] holds in the reference (:16-17,28-36): per evaluation, (in-degree of the fixed
+        entity, 1/rank) and (out-degree, 1/rank) -- two lists in evaluation order, not bucket means."""
+        reciprocal = 1.0 / np.asarray(ranks, dtype=np.float64)
+        return ([(int(deg), float(rr)) for deg, rr in zip(in_degrees, reciprocal)],
+                [(int(deg), float(rr)) for deg, rr in zip(out_degrees, reciprocal)])
 
     @staticmethod
     def get_degree_scores(ranks, in_degrees, out_degrees):
-        """Mean reciprocal rank bucketed by the in- / out-degree of the fixed entity (:38-62)."""
+        """Mean reciprocal rank bucketed by degree (:38-62; not stored in `results` by the reference either).  Bucket
+        label i stands for degree i + 1, as in the reference's lists."""
         res = []
+        reciprocal = 1.0 / np.asarray(ranks, dtype=np.float64)
         for degrees in (in_degrees, out_degrees):
             degrees = np.asarray(degrees, dtype=np.int64)
-            sums = np.bincount(degrees, weights=1.0 / ranks)
-            counts = np.bincount(degrees)
+            if (degrees < 1).any():
+                raise ValueError("degree buckets need degrees >= 1 (the reference indexes bucket degree - 1)")
+            sums = np.bincount(degrees - 1, weights=reciprocal)
+            counts = np.bincount(degrees - 1)
             res.append([(int(i), float(sums[i] / counts[i])) for i in np.flatnonzero(counts)])
         return tuple(res)
+
+    def dump_degrees(self, in_filename, out_filename, filter='Filtered'):
+        """one line per evaluation: label + 1, reciprocal rank (:99-111)"""
+        for filename, pairs in zip((in_filename, out_filename), self.results[filter][self.degree_string()]):
+            with open(filename, 'w+') as f:
+                f.writelines('%s\t%s\n' % (label + 1, value) for label, value in pairs)
+
+    def dump_frequencies(self, vertex_filename, relation_filename, filter='Filtered'):
+        """one line per evaluation: reciprocal rank with the entity's mean relation frequency / the relation's (:117-128)"""
+        rows = self.results[filter][self.freq_string()]
+        with open(vertex_filename, 'w+') as vf, open(relation_filename, 'w+') as rf:
+            for reciprocal, vertex_freq, relation_freq in rows:
+                vf.write('%s\t%s\n' % (reciprocal, vertex_freq))
+                rf.write('%s\t%s\n' % (reciprocal, relation_freq))
 
     def mrr_string(self):
         return 'MRR'

@@ -1,0 +1,183 @@
+"""Host logic against vectors produced by the REFERENCE'S OWN CODE (tests/golden/reference_host_logic.json, made by
+tests/golden/make_reference_fixtures.py, which imports the reference's plain-Python modules where /root/reference
+exists): settings reader + optimizer parameter parser, the Converge stack and fit loop (reporting strings, burn-in,
+early stopping, saving), the negative sampler on numpy's global streams, and the MRR scorer (ranks, ties, filtering,
+degree / frequency bookkeeping, printed summary).  Same inputs through this repository's counterparts, identical
+results demanded.  CPU only; the fixture travels, the reference does not."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from relationprediction_amd.common import auxilliaries, evaluation, optimizer_parameter_parser, settings_reader
+from relationprediction_amd.optimization import optimize
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+with open(os.path.join(HERE, "golden", "reference_host_logic.json")) as _f:
+    FIX = json.load(_f)
+
+COMPONENTS = {"Minibatches", "SampleTransformer", "IterationCounter", "GradientClipping", "Adam", "TrainLossReporter",
+              "EarlyStopper", "ModelSaver", "AdaGrad", "RmsProp", "GradientDescent", "AdditionalOp"}
+
+
+def read_settings(tmp_path, extra):
+    p = tmp_path / "fixture.exp"
+    p.write_text(FIX["settings_text"] % extra)
+    s = settings_reader.read(str(p))
+    s['Optimizer'].merge(s['General'])
+    return s
+
+
+class ScriptedModel(object):
+    def __init__(self, losses):
+        self.losses, self.steps, self.saved = list(losses), 0, []
+
+    def configure_device_optimizer(self, *a):
+        self.cfg = a
+
+    def device_train_step(self, graph, x, y, seed):
+        self.steps += 1
+
+    def device_loss(self):
+        return self.losses[self.steps - 1]
+
+
+def plain(parametrization):
+    out = []
+    for name, params in parametrization:
+        out.append([name, {k: ("<callable>" if callable(v) else v) for k, v in params.items()}])
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(FIX["stack"]))
+def test_converge_stack_behaves_as_the_reference_stack(tmp_path, name):
+    want = FIX["stack"][name]
+    s = read_settings(tmp_path, want["extra"])
+    opp = optimizer_parameter_parser.Parser(s['Optimizer'])
+    model = ScriptedModel(want["losses"])
+    scores = iter(want["scores"])
+    counts = {"transforms": 0, "validations": 0}
+    saves = []
+
+    def transform(x):
+        counts["transforms"] += 1
+        return (x, x, x)
+
+    def score(validation_data):
+        assert validation_data == [3, 4]
+        counts["validations"] += 1
+        return next(scores)
+
+    opp.set_save_function(lambda path: saves.append([path, model.steps]))
+    opp.set_early_stopping_score_function(score)
+    opp.set_sample_transform_function(transform)
+    got = opp.get_parametrization()
+    # the parser: same components, same order, same parameter names and values
+    assert json.loads(json.dumps(plain(got))) == want["parametrization"]
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        iterations = optimize.build_hip(model, got).fit([0, 1, 2], validation_data=[3, 4])
+    # the reference prints each component's name while it builds the stack; everything after that must be identical
+    ref_lines = [l for l in want["stdout"].splitlines() if l not in COMPONENTS]
+    my_lines = [l for l in out.getvalue().splitlines() if l not in COMPONENTS]
+    assert my_lines == ref_lines
+    assert iterations == want["iterations"] == model.steps
+    assert saves == want["saves"]
+    assert counts["validations"] == want["validations"]
+    # this driver asks for the next batch BEFORE it reads the loss of the running step (host work overlaps the
+    # device), so a run that stops on its own has built one batch it never trains on
+    assert counts["transforms"] in (want["transforms"], want["transforms"] + 1)
+
+
+def test_settings_reader_parses_the_shipped_format(tmp_path):
+    """the reference's reader on its own settings/gcn_block.exp (values recorded in the fixture) against this
+    reader on the same keys and values written out in the same format"""
+    want = FIX["gcn_block_exp_parsed"]
+    lines = []
+
+    def emit(d, depth):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                lines.append("\t" * depth + "[%s]" % k)
+                emit(v, depth + 1)
+            else:
+                lines.append("\t" * depth + "%s=%s" % (k, v))
+    emit({k: v for k, v in want.items()}, 0)
+    p = tmp_path / "shipped.exp"
+    p.write_text("\n".join(lines) + "\n")
+    got = settings_reader.read(str(p))
+    import ast
+    assert ast.literal_eval(str(got)) == want
+    assert got['Optimizer']['EarlyStopping']['CheckEvery'] == '2000' and got['General']['GraphBatchSize'] == '30000'
+
+
+@pytest.mark.parametrize("case", FIX["negative_sampler"], ids=lambda c: "seed%d" % c["seed"])
+def test_negative_sampler_equals_the_reference_on_numpy_streams(case):
+    t = np.array(case["triples"], dtype=np.int64)
+    ns = auxilliaries.NegativeSampler(case["rate"], case["entities"])
+    np.random.seed(case["seed"])
+    idx, lab = ns.transform(t)
+    assert str(idx.dtype) == case["index_dtype"] and str(lab.dtype) == case["label_dtype"]
+    assert idx.tolist() == case["indexes"]
+    assert lab.tolist() == case["labels"]
+
+
+def assert_same(got, want, what):
+    """nested lists / tuples / arrays of numbers, equal to within float rounding of the summation order"""
+    if isinstance(want, list):
+        got = list(got)
+        assert len(got) == len(want), what
+        for g, w in zip(got, want):
+            assert_same(g, w, what)
+    else:
+        assert float(got) == pytest.approx(float(want), rel=1e-12, abs=1e-15), what
+
+
+class TableRankModel(object):
+    """device_ranks stand-in on the fixture's score tables: ranks by the oracle's restatement of append_line"""
+
+    def __init__(self, codes, rel, train):
+        self.codes, self.rel, self.test_graph = codes, rel, train
+
+    def device_ranks(self, graph, triplets, predict_object, ptr, idx):
+        known = {}
+        for i, (s, r, o) in enumerate(triplets):
+            known[(s, r) if predict_object else (o, r)] = list(idx[ptr[i]:ptr[i + 1]])
+        return oracle.distmult_ranks(self.codes, self.rel, triplets, predict_object, known)
+
+
+@pytest.mark.parametrize("case", FIX["scorer"], ids=lambda c: "seed%d" % c["seed"])
+def test_scorer_equals_the_reference_scorer(case):
+    V, R, d = case["entities"], case["relations"], case["dim"]
+    rng = np.random.RandomState(case["seed"])
+    mk = lambda n: np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1)  # noqa: E731
+    train, valid, test = (mk(n) for n in case["sizes"])
+    table = np.random.RandomState(case["seed"] + 50)
+    codes = (table.randn(V, d) * case["scale"]).astype(np.float32)
+    rel = table.randn(R, d).astype(np.float32)
+    scorer = evaluation.Scorer({'Metric': 'MRR'})
+    for part in (train, valid, test):
+        scorer.register_data(part)
+    scorer.register_degrees(train)
+    scorer.register_model(TableRankModel(codes, rel, train))
+    scorer.finalize_frequency_computation(np.concatenate((train, valid, test), axis=0))
+    score = scorer.compute_scores(test, verbose=False)
+    n = 2 * len(test)
+    assert [int(x) for x in score.raw_ranks[:n]] == case["raw_ranks"]          # order: per chunk, subjects then objects
+    assert [int(x) for x in score.filtered_ranks[:n]] == case["filtered_ranks"]
+    summary = score.get_summary()
+    assert summary.mrr_string() == case["mrr_string"]
+    for kind in ("Raw", "Filtered"):
+        for key, want in case["results"][kind].items():
+            assert_same(summary.results[kind][key], want, (kind, key))
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        summary.pretty_print()
+    assert out.getvalue() == case["pretty_print"]
+    if case["scale"] > 1:
+        assert np.mean(np.array(case["raw_ranks"]) > 1) > 0.3                   # saturation really produced ties
