@@ -5,7 +5,7 @@
 The encoder arithmetic lives in TensorFlow 1.4 and cannot be run here ("parity unpinned"), but
 the reference's host logic around it is plain Python + numpy and imports as it stands: settings_reader,
 optimizer_parameter_parser, the Converge stack (optimization/abstract.py + shared/algorithms.py + the fit loop and
-the stack constructor of optimization/optimize.py), NegativeSampler, and the MRR Scorer.  This script drives those
+the stack constructor of optimization/optimize.py), NegativeSampler, the MRR Scorer, and (extracted from train.py's source) sample_edge_neighborhood.  This script drives those
 modules on seeded inputs and records what they return / print; tests/test_reference_fixtures.py replays the same
 inputs through this repository's counterparts and demands identical results.  Only theano and tensorflow are
 stubbed (empty modules: the code paths exercised never touch them).  Nothing is copied from the reference: the
@@ -222,12 +222,45 @@ def scorer_cases(m):
     return cases
 
 
+def neighborhood_sampler_cases():
+    """sample_edge_neighborhood lives in the reference's train.py, a script whose top level needs TensorFlow: the
+    function definition and the module-level statements that build its globals (`adj_list`, `degrees`,
+    train.py:133-139) are pulled out of the parsed source and executed on their own -- the reference's code, run
+    as it stands, on numpy's global stream."""
+    import ast
+    tree = ast.parse(open(REF + "/train.py").read())
+    wanted = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "sample_edge_neighborhood":
+            wanted.append(node)
+        elif isinstance(node, ast.Assign):
+            names = {n.id for n in ast.walk(node) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
+            if names & {"adj_list", "degrees"}:
+                wanted.append(node)
+        elif isinstance(node, ast.For):       # the loop that fills adj_list (it only calls .append on it)
+            if any(isinstance(n, ast.Name) and n.id == "adj_list" for n in ast.walk(node)):
+                wanted.append(node)
+    assert [type(n).__name__ for n in wanted] == ["Assign", "For", "Assign", "Assign", "FunctionDef"], wanted
+    code = compile(ast.Module(body=wanted, type_ignores=[]), REF + "/train.py", "exec")
+    cases = []
+    for seed, V, n, size in ((1, 12, 30, 30), (2, 40, 120, 60), (3, 25, 60, 10), (4, 300, 500, 200)):
+        rng = np.random.RandomState(seed)
+        t = np.unique(np.stack([rng.randint(0, V, n), rng.randint(0, 5, n), rng.randint(0, V, n)], 1), axis=0)
+        ns = {"np": np, "entities": list(range(V)), "train_triplets": t}
+        exec(code, ns)
+        np.random.seed(1000 + seed)
+        ids = ns["sample_edge_neighborhood"](t, min(size, len(t)))
+        cases.append({"seed": seed, "entities": V, "triples": t.tolist(), "sample_size": int(min(size, len(t))),
+                      "numpy_seed": 1000 + seed, "edge_ids": [int(i) for i in ids]})
+    return cases
+
+
 def main():
     import tempfile
     m = reference_modules()
     tmp = tempfile.mkdtemp()
     fixture = {"settings_text": SETTINGS_TEXT, "stack": {}, "negative_sampler": negative_sampler_cases(m),
-               "scorer": scorer_cases(m)}
+               "scorer": scorer_cases(m), "neighborhood_sampler": neighborhood_sampler_cases()}
     for name, (extra, losses, scores) in SCENARIOS.items():
         fixture["stack"][name] = run_stack_scenario(m, extra, losses, scores, tmp)
     # the reference's own settings file, as its reader parses it (values only; the file itself is not copied)

@@ -127,6 +127,18 @@ def test_negative_sampler_equals_the_reference_on_numpy_streams(case):
     assert lab.tolist() == case["labels"]
 
 
+@pytest.mark.parametrize("case", FIX["neighborhood_sampler"], ids=lambda c: "seed%d" % c["seed"])
+def test_oracle_sampler_is_the_reference_sampler_draw_for_draw(case):
+    """oracle.sample_edge_neighborhood on numpy's global stream picks exactly the edges the reference's function picks
+    (same seed): the port is exact, so the distribution test of the native O(log V) sampler against the port
+    (tests/test_driver_host.py) is a test against the reference's random process."""
+    t = np.array(case["triples"], dtype=np.int64)
+    np.random.seed(case["numpy_seed"])
+    ids = oracle.sample_edge_neighborhood(t, case["entities"], case["sample_size"], np.random)
+    assert [int(i) for i in ids] == case["edge_ids"]
+    assert len(set(case["edge_ids"])) == len(case["edge_ids"])            # without replacement
+
+
 def assert_same(got, want, what):
     """nested lists / tuples / arrays of numbers, equal to within float rounding of the summation order"""
     if isinstance(want, list):
