@@ -1,7 +1,9 @@
 """CPU oracle: op-for-op numpy/scipy restatement of the reference R-GCN encoder.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED at the TF
-boundary: the reference has no golden vectors and TF 1.4 cannot run here.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED at the TF-kernel
+boundary (the reference has no golden vectors and TF 1.4 cannot run here); pinned above
+it against the reference's own model code run over a numpy stand-in for the TF primitives
+(tests/golden/make_reference_model_fixtures.py, tests/test_reference_model.py).
 
 Every function cites the reference file:line it restates (paths relative to
 the reference checkout, ``code/...``).  The dataflow is deliberately the

@@ -1,0 +1,104 @@
+"""Forward-pass golden vectors computed by THE REFERENCE'S OWN MODEL CODE (run where /root/reference exists):
+
+    python -B tests/golden/make_reference_model_fixtures.py      ->  tests/golden/reference_model.npz
+
+The reference's `common/model_builder.py` assembles Representation -> AffineTransform -> ConcatGcn | BasisGcn x L ->
+RelationEmbedding -> BilinearDiag exactly as `train.py` does; `initialize_train()` draws the weights from numpy's
+global stream; `get_loss('train') + get_regularization()`, `get_all_codes(mode)` and the two score-everything
+graphs are evaluated.  The only thing that is not the reference is TensorFlow itself: `tests/golden/tf_numpy_shim.py`
+is registered as `tensorflow` and evaluates each primitive eagerly in numpy (TF 1.4 cannot be installed here).  What
+this pins: the initial weights (distributions, shapes, creation order = numpy stream order), and the whole
+composition of the forward pass and the loss -- gathers, reshapes, which weight index is the output index, which
+incidence matrix multiplies which messages, where dropout and relu sit.  tests/test_reference_model.py checks the
+oracle (CPU) and the HIP path (`-m gpu`, 1e-4 absolute: north_star's tolerance) against these arrays.
+
+The reference tree is read-only: no bytecode is written (sys.dont_write_bytecode, run with python -B).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/code"
+
+CASES = {
+    # name: (kind, V, R, d, nb|B, L, E, N, seed, sparse_softmax_mode)
+    "block_2layer": ("block", 20, 4, 6, 3, 2, 50, 30, 1, "intended"),
+    "block_sd5": ("block", 30, 7, 10, 2, 2, 120, 40, 2, "intended"),
+    "basis_b2": ("basis", 20, 4, 6, 2, 2, 50, 30, 3, "intended"),
+    "basis_b5_1layer": ("basis", 16, 9, 10, 5, 1, 43, 20, 4, "intended"),      # BASELINE config 1's shape family
+    "block_h1_sorted_rows": ("block", 20, 4, 6, 3, 2, 50, 30, 5, "sorted_rows"),
+}
+
+
+def settings_for(kind, V, R, d, nb, L, E):
+    enc = {'Name': 'gcn_basis', 'DropoutKeepProbability': '0.8', 'InternalEncoderDimension': str(d),
+           'NumberOfBasisFunctions': str(nb), 'NumberOfLayers': str(L), 'UseInputTransform': 'Yes',
+           'UseOutputTransform': 'No', 'AddDiagonal': 'No', 'DiagonalCoefficients': 'No', 'SkipConnections': 'None',
+           'StoreEdgeData': 'No', 'RandomInput': 'No', 'PartiallyRandomInput': 'No',
+           'Concatenation': 'Yes' if kind == 'block' else 'No', 'CodeDimension': str(d),
+           'EntityCount': V, 'RelationCount': R, 'EdgeCount': E, 'NegativeSampleRate': '10', 'GraphSplitSize': '0.5'}
+    dec = {'Name': 'bilinear-diag', 'RegularizationParameter': '0.01', 'CodeDimension': str(d),
+           'EntityCount': V, 'RelationCount': R, 'EdgeCount': E, 'NegativeSampleRate': '10'}
+    return enc, dec
+
+
+def main():
+    sys.path.insert(0, HERE)
+    import tf_numpy_shim as tf
+    sys.modules['tensorflow'] = tf
+    for stub in ("theano", "theano.tensor"):
+        sys.modules.setdefault(stub, types.ModuleType(stub))
+    sys.modules["theano"].tensor = sys.modules["theano.tensor"]
+    sys.path.insert(0, REF)
+    from common import model_builder                       # the reference's
+    from encoders.message_gcns.message_gcn import MessageGcn
+    from decoders.bilinear_diag import BilinearDiag
+
+    out = {}
+    for name, (kind, V, R, d, nb, L, E, N, seed, mode) in CASES.items():
+        rng = np.random.RandomState(100 + seed)
+        triples = np.stack([rng.randint(0, V, E), rng.randint(0, R, E), rng.randint(0, V, E)], 1).astype(np.int32)
+        X = np.stack([rng.randint(0, V, N), rng.randint(0, R, N), rng.randint(0, V, N)], 1).astype(np.int32)
+        X[:N // 3] = triples[:N // 3]
+        Y = (np.arange(N) < N // 3).astype(np.float32)
+        tf.reset({'graph_edges': triples, 'X': X, 'Y': Y}, dropout_seed=seed, sparse_softmax_mode=mode)
+        # the reference keeps its per-mode caches in CLASS attributes: fresh ones for every model
+        MessageGcn.vertex_embedding_function = {'train': None, 'test': None}
+        BilinearDiag.encoder_cache = {'train': None, 'test': None}
+        enc, dec = settings_for(kind, V, R, d, nb, L, E)
+        np.random.seed(seed)
+        encoder = model_builder.build_encoder(enc, triples)
+        model = model_builder.build_decoder(encoder, dec)
+        model.preprocess(triples)
+        model.register_for_test(triples)
+        model.initialize_train()
+        weights = [np.array(w) for w in model.get_weights()]
+        loss = model.get_loss(mode='train') + model.get_regularization()      # train.py's loss
+        codes_train = np.array(encoder.get_all_codes(mode='train')[0])
+        masks = [np.array(m) for m in tf.DROPOUT_MASKS]                        # call order: bottom GCN layer first
+        assert len(masks) == L, (name, len(masks))
+        codes_test = np.array(encoder.get_all_codes(mode='test')[0])
+        assert len(tf.DROPOUT_MASKS) == L                                      # test mode draws nothing
+        subj = np.array(model.predict_all_subject_scores())
+        obj = np.array(model.predict_all_object_scores())
+        out[name + "/config"] = np.array([{'block': 0, 'basis': 1}[kind], V, R, d, nb, L, E, N, seed,
+                                          {'intended': 0, 'sorted_rows': 1}[mode]], dtype=np.int64)
+        out[name + "/triples"], out[name + "/X"], out[name + "/Y"] = triples, X, Y
+        for i, w in enumerate(weights):
+            out["%s/weight%02d" % (name, i)] = w
+        for i, m in enumerate(masks):
+            out["%s/mask%d" % (name, i + 1)] = m
+        out[name + "/loss_train"] = np.float64(loss)
+        out[name + "/codes_train"], out[name + "/codes_test"] = codes_train, codes_test
+        out[name + "/subject_scores"], out[name + "/object_scores"] = subj, obj
+        print(name, "weights", [w.shape for w in weights], "loss %.6f" % loss, "codes", codes_test.shape)
+    np.savez_compressed(os.path.join(HERE, "reference_model.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""The oracle (CPU) and the HIP path (`-m gpu`) against forward passes computed by THE REFERENCE'S OWN MODEL CODE.
+
+tests/golden/reference_model.npz is made by tests/golden/make_reference_model_fixtures.py: the reference's
+model_builder / Representation / AffineTransform / ConcatGcn / BasisGcn / RelationEmbedding / BilinearDiag run as
+they stand, with an eager numpy stand-in for the ~25 TensorFlow primitives they call (TF 1.4 cannot be installed).
+Pinned here: initial weights bit for bit on numpy's global stream (distributions, shapes, creation order), codes in
+test and train mode (the dropout masks the reference drew are injected), the training loss with its regulariser, and
+the score-every-subject / score-every-object matrices -- i.e. the composition of the reference's dataflow, which
+index of W is the output index, which incidence matrix multiplies which messages, where dropout and relu sit."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = np.load(os.path.join(HERE, "golden", "reference_model.npz"))
+CASES = sorted({k.split("/")[0] for k in FIX.files})
+FWD_ATOL = 1e-4            # north_star: "outputs match the reference forward pass within 1e-4 fp32"
+
+
+def load(name):
+    kind_id, V, R, d, nb, L, E, N, seed, mode = (int(x) for x in FIX[name + "/config"])
+    kind = "block" if kind_id == 0 else "basis"
+    names = oracle.weight_names(kind, L)
+    weights = [FIX["%s/weight%02d" % (name, i)] for i in range(len(names))]
+    assert "%s/weight%02d" % (name, len(names)) not in FIX.files              # the reference holds exactly these
+    c = dict(kind=kind, V=V, R=R, d=d, nb=nb, L=L, E=E, N=N, seed=seed,
+             norm="intended" if mode == 0 else "tf_as_executed",
+             params=dict(zip(names, weights)), names=names,
+             triples=FIX[name + "/triples"], X=FIX[name + "/X"], Y=FIX[name + "/Y"],
+             masks=[FIX["%s/mask%d" % (name, l)] for l in range(1, L + 1)])
+    for key in ("loss_train", "codes_train", "codes_test", "subject_scores", "object_scores"):
+        c[key] = FIX[name + "/" + key]
+    return c
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_initial_weights_are_the_reference_draws(name):
+    """same seed, same numpy global stream: the oracle's init_params (and through it the plugin chain, whose
+    stream consumption tests/test_plugin_surface.py ties to init_params) reproduces the reference's variables exactly"""
+    c = load(name)
+    np.random.seed(c["seed"])
+    mine = oracle.init_params(c["V"], c["R"], c["d"], c["L"], c["kind"], c["nb"], rng=np.random)
+    for n in c["names"]:
+        assert mine[n].dtype == c["params"][n].dtype == np.float32, n
+        np.testing.assert_array_equal(mine[n], c["params"][n], err_msg=n)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_forward_and_loss_equal_the_reference_dataflow(name):
+    c = load(name)
+    test = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="test",
+                                  norm_mode=c["norm"])
+    assert float(np.abs(test[-1] - c["codes_test"]).max()) <= 2e-6 * max(1.0, float(np.abs(c["codes_test"]).max()))
+    train = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="train", keep_prob=0.8,
+                                   dropout_masks=c["masks"], norm_mode=c["norm"])
+    assert float(np.abs(train[-1] - c["codes_train"]).max()) <= 2e-6 * max(1.0, float(np.abs(c["codes_train"]).max()))
+    loss, _, _ = oracle.distmult_loss_and_grads(train[-1], c["params"]["W_relation"], c["X"], c["Y"], 0.01)
+    assert loss == pytest.approx(float(c["loss_train"]), rel=2e-6)
+    # score-everything graphs (bilinear_diag.py:46-61): row i = sigmoid energies of every entity in triple i's open slot
+    codes, rel = test[-1], c["params"]["W_relation"]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))  # noqa: E731
+    subj = np.stack([sig(codes @ (rel[r] * codes[o])) for s, r, o in c["X"]])
+    obj = np.stack([sig(codes @ (codes[s] * rel[r])) for s, r, o in c["X"]])
+    assert np.abs(subj - c["subject_scores"]).max() <= 1e-5 and np.abs(obj - c["object_scores"]).max() <= 1e-5
+
+
+def test_the_two_h1_readings_differ_and_the_fixture_covers_both():
+    """the 'sorted_rows' case is the reference's graph under the suspected behaviour of
+    tf.sparse_softmax on non-canonical indices; the oracle's tf_as_executed mode must follow it, the intended mode
+    must NOT (otherwise the case would not discriminate)."""
+    c = load("block_h1_sorted_rows")
+    assert c["norm"] == "tf_as_executed"
+    other = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="test",
+                                   norm_mode="intended")
+    assert float(np.abs(other[-1] - c["codes_test"]).max()) > 1e-3
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_path_equals_the_reference_dataflow(native, name):
+    """through the C ABI: codes in both modes within 1e-4 absolute of what the reference's own model code computed,
+    the training loss (decoder + regulariser), and raw ranks from the reference's score matrices"""
+    c = load(name)
+    eng = native.Engine(c["V"], c["R"], c["d"], c["L"], c["kind"], c["nb"], keep_prob=0.8, norm_mode=c["norm"],
+                        max_edges=c["E"])
+    bufs = []
+    try:
+        eng.set_params(c["params"])
+        eng.set_graph(c["triples"])
+        eng.forward(train=False)
+        assert float(np.abs(eng.codes() - c["codes_test"]).max()) <= FWD_ATOL
+        # ranks straight from the reference's score matrices: number of entities scoring >= the gold one
+        eng.rank_reserve(len(c["X"]))
+        ptr = np.arange(len(c["X"]) + 1, dtype=np.int64)
+        for object_side, scores, gold_col in ((True, c["object_scores"], 2), (False, c["subject_scores"], 0)):
+            gold = c["X"][:, gold_col]
+            want = (scores >= scores[np.arange(len(gold)), gold][:, None]).sum(1)
+            raw, filt = eng.ranks(c["X"], object_side, ptr, gold.astype(np.int32))      # filter list = the gold entity
+            assert np.abs(raw - want).max() <= 1 and np.mean(raw != want) <= 0.05        # fp32 near-ties may move a rank
+            assert np.array_equal(raw, filt)
+        eng.forward(train=True, masks=c["masks"])
+        assert float(np.abs(eng.codes() - c["codes_train"]).max()) <= FWD_ATOL
+        eng.decoder_reserve(len(c["X"]))
+        xd, yd = eng.to_device(np.ascontiguousarray(c["X"])), eng.to_device(np.ascontiguousarray(c["Y"]))
+        bufs += [xd, yd]
+        eng.decoder_loss_backward_device(xd, yd, len(c["X"]), 0.01)
+        assert eng.loss() == pytest.approx(float(c["loss_train"]), rel=2e-5)
+    finally:
+        for b in bufs:
+            b.free()
+        eng.close()
