@@ -9,7 +9,9 @@ graphs are evaluated.  The only thing that is not the reference is TensorFlow it
 is registered as `tensorflow` and evaluates each primitive eagerly in numpy (TF 1.4 cannot be installed here).  What
 this pins: the initial weights (distributions, shapes, creation order = numpy stream order), and the whole
 composition of the forward pass and the loss -- gathers, reshapes, which weight index is the output index, which
-incidence matrix multiplies which messages, where dropout and relu sit.  tests/test_reference_model.py checks the
+incidence matrix multiplies which messages, where dropout and relu sit -- and, through a second run of the same model
+code on torch tensors (tf_torch_shim.py), the gradient of that loss w.r.t. every weight: what tf.gradients(loss,
+weights) differentiates (optimization/abstract.py:117-118), by autograd over the reference's own dataflow.  tests/test_reference_model.py checks the
 oracle (CPU) and the HIP path (`-m gpu`, 1e-4 absolute: north_star's tolerance) against these arrays.
 
 The reference tree is read-only: no bytecode is written (sys.dont_write_bytecode, run with python -B).
@@ -96,7 +98,38 @@ def main():
         out[name + "/loss_train"] = np.float64(loss)
         out[name + "/codes_train"], out[name + "/codes_test"] = codes_train, codes_test
         out[name + "/subject_scores"], out[name + "/object_scores"] = subj, obj
-        print(name, "weights", [w.shape for w in weights], "loss %.6f" % loss, "codes", codes_test.shape)
+        # ---- the same graph once more on torch tensors: tf.gradients(loss, weights) = autograd over the
+        # reference's own dataflow (same weights: same seed; same dropout masks: replayed)
+        import tf_torch_shim as tft
+        ref_modules = [m for m in list(sys.modules.values())
+                       if getattr(m, '__file__', None) and str(m.__file__).startswith(REF) and hasattr(m, 'tf')]
+        for m in ref_modules:
+            m.tf = tft
+        try:
+            tft.reset({'graph_edges': triples, 'X': X, 'Y': Y}, masks, sparse_softmax_mode=mode)
+            MessageGcn.vertex_embedding_function = {'train': None, 'test': None}
+            BilinearDiag.encoder_cache = {'train': None, 'test': None}
+            np.random.seed(seed)
+            encoder_t = model_builder.build_encoder(enc, triples)
+            model_t = model_builder.build_decoder(encoder_t, dec)
+            model_t.preprocess(triples)
+            model_t.register_for_test(triples)
+            model_t.initialize_train()
+            weights_t = model_t.get_weights()
+            for w_np, w_t in zip(weights, weights_t):
+                assert np.array_equal(w_np, w_t.detach().numpy())
+            loss_t = model_t.get_loss(mode='train') + model_t.get_regularization()
+            assert abs(float(loss_t) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (float(loss_t), float(loss))
+            loss_t.backward()
+            for i, w_t in enumerate(weights_t):
+                connected = w_t.grad is not None
+                out["%s/grad%02d" % (name, i)] = (w_t.grad.numpy() if connected else np.zeros_like(weights[i]))
+                out["%s/grad%02d_connected" % (name, i)] = np.array(connected)
+        finally:
+            for m in ref_modules:
+                m.tf = tf
+        print(name, "weights", [w.shape for w in weights], "loss %.6f" % loss, "codes", codes_test.shape,
+              "unconnected", [i for i, w_t in enumerate(weights_t) if w_t.grad is None])
     np.savez_compressed(os.path.join(HERE, "reference_model.npz"), **out)
 
 

@@ -44,8 +44,16 @@ def placeholder(dtype, shape=None, name=None):
     return np.asarray(FEED['X'], dtype=np.int32)
 
 
+class _Tensor(np.ndarray):
+    """`x += y` on a TF tensor builds a new tensor; the reference relies on that (affine_transform.py:72-76 adds the
+    bias to `hidden = self.W`), so in-place addition must not write into the variable"""
+
+    def __iadd__(self, other):
+        return np.add(self, other)
+
+
 def Variable(initial_value, *args, **kwargs):
-    return np.array(initial_value)
+    return np.array(initial_value).view(_Tensor)
 
 
 def to_float(x):

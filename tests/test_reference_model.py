@@ -33,7 +33,14 @@ def load(name):
              masks=[FIX["%s/mask%d" % (name, l)] for l in range(1, L + 1)])
     for key in ("loss_train", "codes_train", "codes_test", "subject_scores", "object_scores"):
         c[key] = FIX[name + "/" + key]
+    c["grads"] = {n: FIX["%s/grad%02d" % (name, i)] for i, n in enumerate(names)}
+    c["connected"] = {n: bool(FIX["%s/grad%02d_connected" % (name, i)]) for i, n in enumerate(names)}
     return c
+
+
+def assert_grad_close(got, want, what, rel=2e-4):
+    scale = max(float(np.abs(want).max()), 1e-6)
+    assert float(np.abs(got - want).max()) <= rel * scale + 1e-7, (what, float(np.abs(got - want).max()), scale)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -65,6 +72,26 @@ def test_oracle_forward_and_loss_equal_the_reference_dataflow(name):
     subj = np.stack([sig(codes @ (rel[r] * codes[o])) for s, r, o in c["X"]])
     obj = np.stack([sig(codes @ (codes[s] * rel[r])) for s, r, o in c["X"]])
     assert np.abs(subj - c["subject_scores"]).max() <= 1e-5 and np.abs(obj - c["object_scores"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_gradients_equal_autograd_of_the_reference_dataflow(name):
+    """tf.gradients(loss, weights) (optimization/abstract.py:117-118), obtained by running the reference's model code
+    on torch tensors: every weight's gradient, the decoder's included; the variables the reference's graph leaves
+    unconnected are exactly the per-layer biases"""
+    c = load(name)
+    assert sorted(n for n, ok in c["connected"].items() if not ok) == sorted("b%d" % l for l in range(1, c["L"] + 1))
+    acts = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="train", keep_prob=0.8,
+                                  dropout_masks=c["masks"], norm_mode=c["norm"])
+    _, dcodes, d_rel = oracle.distmult_loss_and_grads(acts[-1], c["params"]["W_relation"], c["X"], c["Y"], 0.01)
+    grads = oracle.encoder_backward(c["params"], c["triples"], c["V"], c["L"], c["kind"], acts, dcodes, mode="train",
+                                    keep_prob=0.8, dropout_masks=c["masks"], norm_mode=c["norm"])
+    grads["W_relation"] = d_rel
+    for n in c["names"]:
+        if c["connected"][n]:
+            assert_grad_close(grads[n], c["grads"][n], n, rel=2e-5)
+        else:
+            assert not np.asarray(grads[n]).any(), n
 
 
 def test_the_two_h1_readings_differ_and_the_fixture_covers_both():
@@ -115,6 +142,14 @@ def test_hip_path_equals_the_reference_dataflow(native, name):
         bufs += [xd, yd]
         eng.decoder_loss_backward_device(xd, yd, len(c["X"]), 0.01)
         assert eng.loss() == pytest.approx(float(c["loss_train"]), rel=2e-5)
+        # and the gradient of that loss w.r.t. every weight: autograd over the reference's own dataflow
+        eng.backward_from_decoder()
+        grads = eng.get_grads()
+        for n in c["names"]:
+            if c["connected"][n]:
+                assert_grad_close(grads[n], c["grads"][n], n)
+            elif n in grads:
+                assert not grads[n].any(), n
     finally:
         for b in bufs:
             b.free()
