@@ -34,7 +34,19 @@ CASES = {
     "basis_b2": ("basis", 20, 4, 6, 2, 2, 50, 30, 3, "intended"),
     "basis_b5_1layer": ("basis", 16, 9, 10, 5, 1, 43, 20, 4, "intended"),      # BASELINE config 1's shape family
     "block_h1_sorted_rows": ("block", 20, 4, 6, 3, 2, 50, 30, 5, "sorted_rows"),
+    # BASELINE config 2 at full size: the real FB15k-237 minibatch graph of tests/golden/graphs.npz, d = 500, 100
+    # blocks of 5x5, 2 layers; stored as fingerprints (weights and masks are regenerated from the seeds by the test)
+    "fb237_block_full": ("block", 14541, 237, 500, 100, 2, 15000, 3000, 6, "intended"),
 }
+FULL_SIZE = {"fb237_block_full": "fb237_minibatch"}
+
+
+def fingerprint(arr, n=256, seed=0):
+    """tests/helpers.py:probe -- l2 norm, sum and n sampled entries at fixed positions"""
+    a = np.asarray(arr, dtype=np.float32).ravel()
+    idx = np.random.RandomState(seed).randint(0, a.size, size=min(n, a.size))
+    return {"l2": np.float64(np.sqrt(np.sum(a.astype(np.float64) ** 2))), "sum": np.float64(a.astype(np.float64).sum()),
+            "idx": idx.astype(np.int64), "val": a[idx].copy()}
 
 
 def settings_for(kind, V, R, d, nb, L, E):
@@ -65,6 +77,11 @@ def main():
     for name, (kind, V, R, d, nb, L, E, N, seed, mode) in CASES.items():
         rng = np.random.RandomState(100 + seed)
         triples = np.stack([rng.randint(0, V, E), rng.randint(0, R, E), rng.randint(0, V, E)], 1).astype(np.int32)
+        full = name in FULL_SIZE
+        if full:
+            with np.load(os.path.join(HERE, "graphs.npz")) as z:
+                triples = z[FULL_SIZE[name]].astype(np.int32)
+            assert triples.shape == (E, 3)
         X = np.stack([rng.randint(0, V, N), rng.randint(0, R, N), rng.randint(0, V, N)], 1).astype(np.int32)
         X[:N // 3] = triples[:N // 3]
         Y = (np.arange(N) < N // 3).astype(np.float32)
@@ -86,18 +103,34 @@ def main():
         assert len(masks) == L, (name, len(masks))
         codes_test = np.array(encoder.get_all_codes(mode='test')[0])
         assert len(tf.DROPOUT_MASKS) == L                                      # test mode draws nothing
-        subj = np.array(model.predict_all_subject_scores())
-        obj = np.array(model.predict_all_object_scores())
+        subj = obj = None
+        if name not in FULL_SIZE:
+            subj = np.array(model.predict_all_subject_scores())
+            obj = np.array(model.predict_all_object_scores())
         out[name + "/config"] = np.array([{'block': 0, 'basis': 1}[kind], V, R, d, nb, L, E, N, seed,
                                           {'intended': 0, 'sorted_rows': 1}[mode]], dtype=np.int64)
-        out[name + "/triples"], out[name + "/X"], out[name + "/Y"] = triples, X, Y
-        for i, w in enumerate(weights):
-            out["%s/weight%02d" % (name, i)] = w
-        for i, m in enumerate(masks):
-            out["%s/mask%d" % (name, i + 1)] = m
+        out[name + "/X"], out[name + "/Y"] = X, Y
+        if not full:
+            out[name + "/triples"] = triples            # (the full-size graph is already in graphs.npz)
+        def store(key, arr):
+            if full:
+                for field, v in fingerprint(arr).items():
+                    out["%s/%s/%s" % (name, key, field)] = v
+            else:
+                out["%s/%s" % (name, key)] = arr
+        if not full:
+            for i, w in enumerate(weights):
+                out["%s/weight%02d" % (name, i)] = w
+            for i, m in enumerate(masks):
+                out["%s/mask%d" % (name, i + 1)] = m
+            out[name + "/subject_scores"], out[name + "/object_scores"] = subj, obj
+        else:
+            out[name + "/n_weights"] = np.int64(len(weights))
+            for i, w in enumerate(weights):
+                store("weight%02d" % i, w)
         out[name + "/loss_train"] = np.float64(loss)
-        out[name + "/codes_train"], out[name + "/codes_test"] = codes_train, codes_test
-        out[name + "/subject_scores"], out[name + "/object_scores"] = subj, obj
+        store("codes_train", codes_train)
+        store("codes_test", codes_test)
         # ---- the same graph once more on torch tensors: tf.gradients(loss, weights) = autograd over the
         # reference's own dataflow (same weights: same seed; same dropout masks: replayed)
         import tf_torch_shim as tft
@@ -123,7 +156,7 @@ def main():
             loss_t.backward()
             for i, w_t in enumerate(weights_t):
                 connected = w_t.grad is not None
-                out["%s/grad%02d" % (name, i)] = (w_t.grad.numpy() if connected else np.zeros_like(weights[i]))
+                store("grad%02d" % i, w_t.grad.numpy() if connected else np.zeros_like(weights[i]))
                 out["%s/grad%02d_connected" % (name, i)] = np.array(connected)
         finally:
             for m in ref_modules:

@@ -16,7 +16,8 @@ import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = np.load(os.path.join(HERE, "golden", "reference_model.npz"))
-CASES = sorted({k.split("/")[0] for k in FIX.files})
+FULL = "fb237_block_full"                     # stored as fingerprints; weights and masks regenerated from the seeds
+CASES = sorted({k.split("/")[0] for k in FIX.files} - {FULL})
 FWD_ATOL = 1e-4            # north_star: "outputs match the reference forward pass within 1e-4 fp32"
 
 
@@ -103,6 +104,86 @@ def test_the_two_h1_readings_differ_and_the_fixture_covers_both():
     other = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="test",
                                    norm_mode="intended")
     assert float(np.abs(other[-1] - c["codes_test"]).max()) > 1e-3
+
+
+# ------------------------------------------------------------------ BASELINE config 2 at full size
+def load_full():
+    import helpers
+    kind_id, V, R, d, nb, L, E, N, seed, mode = (int(x) for x in FIX[FULL + "/config"])
+    assert (kind_id, mode) == (0, 0)
+    names = oracle.weight_names("block", L)
+    assert int(FIX[FULL + "/n_weights"]) == len(names)
+    np.random.seed(seed)                                         # the reference's draws (bitwise: the small cases)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=np.random)
+    drop = np.random.RandomState(seed)                           # the shim's dropout stream, bottom layer first
+    masks = [np.floor(0.8 + drop.uniform(size=(V, d))).astype(np.uint8) for _ in range(L)]
+    fp = lambda key: {f: FIX["%s/%s/%s" % (FULL, key, f)] for f in ("l2", "sum", "idx", "val")}  # noqa: E731
+    return dict(V=V, R=R, d=d, nb=nb, L=L, E=E, names=names, params=params, masks=masks,
+                triples=helpers.load_graph("fb237_minibatch"), X=FIX[FULL + "/X"], Y=FIX[FULL + "/Y"],
+                loss=float(FIX[FULL + "/loss_train"]), fp=fp,
+                connected=[bool(FIX["%s/grad%02d_connected" % (FULL, i)]) for i in range(len(names))])
+
+
+def check_codes(codes, pr, atol):
+    a = np.asarray(codes, dtype=np.float32).ravel()
+    assert float(np.abs(a[pr["idx"]] - pr["val"]).max()) <= atol
+    l2 = float(np.sqrt(np.sum(a.astype(np.float64) ** 2)))
+    assert abs(l2 - float(pr["l2"])) <= 1e-5 * float(pr["l2"])
+
+
+def test_full_size_oracle_equals_the_reference_dataflow():
+    """FB15k-237 gcn_block at full size (V 14,541, d 500, 100 blocks, 2 layers, the real 15,000-edge minibatch): the
+    reference's own model code computed these fingerprints; the oracle must land on them -- weights, codes in both
+    modes, loss, every gradient."""
+    import helpers
+    c = load_full()
+    for i, n in enumerate(c["names"]):
+        pr = c["fp"]("weight%02d" % i)
+        flat = c["params"][n].ravel()
+        assert np.array_equal(flat[pr["idx"]], pr["val"]), n                       # bitwise at the sampled positions
+    test = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], "block", mode="test")
+    check_codes(test[-1], c["fp"]("codes_test"), 2e-5)
+    acts = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], "block", mode="train", keep_prob=0.8,
+                                  dropout_masks=c["masks"])
+    check_codes(acts[-1], c["fp"]("codes_train"), 2e-5)
+    loss, dcodes, d_rel = oracle.distmult_loss_and_grads(acts[-1], c["params"]["W_relation"], c["X"], c["Y"], 0.01)
+    assert loss == pytest.approx(c["loss"], rel=1e-5)
+    grads = oracle.encoder_backward(c["params"], c["triples"], c["V"], c["L"], "block", acts, dcodes, mode="train",
+                                    keep_prob=0.8, dropout_masks=c["masks"])
+    grads["W_relation"] = d_rel
+    for i, n in enumerate(c["names"]):
+        if c["connected"][i]:
+            helpers.check_probe(grads[n], c["fp"]("grad%02d" % i), rel=1e-4, name=n)
+
+
+@pytest.mark.gpu
+def test_full_size_hip_path_equals_the_reference_dataflow(native):
+    """the same fingerprints through the C ABI: codes within 1e-4 absolute (north_star), loss, all gradients"""
+    import helpers
+    c = load_full()
+    eng = native.Engine(c["V"], c["R"], c["d"], c["L"], "block", c["nb"], keep_prob=0.8, max_edges=c["E"])
+    bufs = []
+    try:
+        eng.set_params(c["params"])
+        eng.set_graph(c["triples"])
+        eng.forward(train=False)
+        check_codes(eng.codes(), c["fp"]("codes_test"), FWD_ATOL)
+        eng.forward(train=True, masks=c["masks"])
+        check_codes(eng.codes(), c["fp"]("codes_train"), FWD_ATOL)
+        eng.decoder_reserve(len(c["X"]))
+        xd, yd = eng.to_device(np.ascontiguousarray(c["X"])), eng.to_device(np.ascontiguousarray(c["Y"]))
+        bufs += [xd, yd]
+        eng.decoder_loss_backward_device(xd, yd, len(c["X"]), 0.01)
+        assert eng.loss() == pytest.approx(c["loss"], rel=2e-5)
+        eng.backward_from_decoder()
+        grads = eng.get_grads()
+        for i, n in enumerate(c["names"]):
+            if c["connected"][i]:
+                helpers.check_probe(grads[n], c["fp"]("grad%02d" % i), name=n)    # isolated relu-gate flips tolerated
+    finally:
+        for b in bufs:
+            b.free()
+        eng.close()
 
 
 @pytest.fixture(scope="module")
