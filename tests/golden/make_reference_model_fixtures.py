@@ -34,6 +34,12 @@ CASES = {
     "basis_b2": ("basis", 20, 4, 6, 2, 2, 50, 30, 3, "intended"),
     "basis_b5_1layer": ("basis", 16, 9, 10, 5, 1, 43, 20, 4, "intended"),      # BASELINE config 1's shape family
     "block_h1_sorted_rows": ("block", 20, 4, 6, 3, 2, 50, 30, 5, "sorted_rows"),
+    # corners where tf.squeeze (drops EVERY size-1 dimension) and the reshapes could bite
+    "block_one_edge": ("block", 12, 3, 6, 3, 2, 1, 8, 7, "intended"),
+    "block_sd1": ("block", 15, 3, 6, 6, 2, 40, 12, 8, "intended"),            # 1x1 blocks
+    "block_nb1": ("block", 15, 3, 4, 1, 2, 40, 12, 9, "intended"),            # one 4x4 block = a dense W per relation
+    "basis_b1": ("basis", 15, 3, 6, 1, 2, 40, 12, 10, "intended"),
+    "basis_h1_sorted_rows": ("basis", 20, 4, 6, 2, 2, 50, 30, 11, "sorted_rows"),
     # BASELINE config 2 at full size: the real FB15k-237 minibatch graph of tests/golden/graphs.npz, d = 500, 100
     # blocks of 5x5, 2 layers; stored as fingerprints (weights and masks are regenerated from the seeds by the test)
     "fb237_block_full": ("block", 14541, 237, 500, 100, 2, 15000, 3000, 6, "intended"),
