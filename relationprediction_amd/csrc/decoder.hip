@@ -450,6 +450,103 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_rel_partial(const float* __
 }
 
 // gWr[r] = sum of r's chunk slabs (chunk order) + k cnt_r Wr[r];   rows >= R of W_relation are never used
+// ---- K1 fused with the relation gradient's partials ------------------------------------------------------
+// One workgroup per relation chunk (<= kDecChunk triples of ONE relation, in the order of the relation sort): each
+// wave takes every fourth triple, keeps the relation's row and the two entity rows in registers (column c of a row
+// lives in lane c mod 64, as in k_dec_energy, so the energy is the same number bit for bit), reduces the energy over
+// the wave, and -- the point of the fusion -- adds g * e1 * e2 to its register accumulators while the rows are still
+// there, instead of a second kernel gathering both rows again (0.2 ms at N = 330,000, and it used to run beside the
+// encoder's backward pass and slow its GEMMs).  The four waves' accumulators are summed in a fixed order into the
+// chunk's slab row; k_dec_rel_reduce finishes as before.  T = ceil(d / VEC / 64) <= 4; wider rows use the two
+// separate kernels.
+template <int VEC, int T>
+__global__ void __launch_bounds__(256) k_dec_energy_rel(const float* __restrict__ codes, const float* __restrict__ Wr,
+                                                        const int32_t* __restrict__ X, const float* __restrict__ Y,
+                                                        const int32_t* __restrict__ permr,
+                                                        const int32_t* __restrict__ rel_ptr,
+                                                        const int32_t* __restrict__ chunk_ptr, int N, int R, int d,
+                                                        float* __restrict__ dx, float* __restrict__ part,
+                                                        float* __restrict__ slab) {
+  extern __shared__ float sm[];                      // [4][d] wave accumulators, then [4][2] loss terms
+  const int bid = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (bid >= chunk_ptr[R]) {
+    if (threadIdx.x < 2) part[(size_t)bid * 2 + threadIdx.x] = 0.f;
+    return;
+  }
+  const int rel = find_segment(chunk_ptr, R, bid);
+  const int beg = rel_ptr[rel] + (bid - chunk_ptr[rel]) * kDecChunk;
+  const int end = min(beg + kDecChunk, rel_ptr[rel + 1]);
+  const int nvec = d / VEC;
+  float rr[T][VEC], acc[T][VEC];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int c = lane + 64 * t;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { rr[t][k] = 0.f; acc[t][k] = 0.f; }
+    if (c < nvec) vload<VEC>(Wr + (size_t)rel * d + (size_t)c * VEC, rr[t]);
+  }
+  float xent = 0.f, sq = 0.f;                        // accumulated by lane 0 of each wave
+  for (int j = beg + wave; j < end; j += 4) {
+    const int n = permr[j];
+    const int s = X[3 * n], o = X[3 * n + 2];        // in range: invalid triples sort behind rel_ptr[R]
+    const float* p1 = codes + (size_t)s * d;
+    const float* p2 = codes + (size_t)o * d;
+    float a[T][VEC], e[T][VEC];
+    float x = 0.f, q = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int c = lane + 64 * t;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { a[t][k] = 0.f; e[t][k] = 0.f; }
+      if (c < nvec) {
+        vload<VEC>(p1 + (size_t)c * VEC, a[t]);
+        vload<VEC>(p2 + (size_t)c * VEC, e[t]);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          x = fmaf(a[t][k] * rr[t][k], e[t][k], x);
+          q += a[t][k] * a[t][k] + rr[t][k] * rr[t][k] + e[t][k] * e[t][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      x += __shfl_down(x, off, 64);
+      q += __shfl_down(q, off, 64);
+    }
+    float g = 0.f;
+    if (lane == 0) {
+      const float y = Y[n];
+      const float ax = fabsf(x);
+      const float ex = __expf(-ax);
+      const float sig = x >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
+      g = (sig - y) / (float)N;
+      dx[n] = g;
+      xent += (1.0f - y) * x + log1pf(ex) + fmaxf(-x, 0.f);
+      sq += q;
+    }
+    g = __shfl(g, 0, 64);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[t][k] = fmaf(g * a[t][k], e[t][k], acc[t][k]);
+  }
+  float* red = sm;
+  float* lossred = sm + (size_t)4 * d;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int c = lane + 64 * t;
+    if (c < nvec) vstore<VEC>(red + (size_t)wave * d + (size_t)c * VEC, acc[t]);
+  }
+  if (lane == 0) { lossred[wave * 2] = xent; lossred[wave * 2 + 1] = sq; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nvec * VEC; i += 256)
+    slab[(size_t)bid * d + i] = ((red[i] + red[d + i]) + red[2 * (size_t)d + i]) + red[3 * (size_t)d + i];
+  if (threadIdx.x < 2)
+    part[(size_t)bid * 2 + threadIdx.x] = ((lossred[threadIdx.x] + lossred[2 + threadIdx.x]) + lossred[4 + threadIdx.x]) +
+                                          lossred[6 + threadIdx.x];
+}
+
 __global__ void k_dec_rel_reduce(const float* __restrict__ slab, const int32_t* __restrict__ chunk_ptr,
                                  const int32_t* __restrict__ rel_ptr, const float* __restrict__ Wr,
                                  float* __restrict__ gWr, int R, int d, float k) {
@@ -517,9 +614,9 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.nlong, 2));
   RGCN_TRY(dalloc(c, &q.dx, N));
   q.energy_blocks = 2048;
-  RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)q.energy_blocks));
-  RGCN_TRY(dalloc(c, &q.loss, 1));
   q.max_chunks = (int32_t)(N / kDecChunk + R + 1);
+  RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)(q.energy_blocks > q.max_chunks ? q.energy_blocks : q.max_chunks)));
+  RGCN_TRY(dalloc(c, &q.loss, 1));
   RGCN_TRY(dalloc(c, &q.slab, (size_t)q.max_chunks * d));
   size_t t1 = 0, t2 = 0;
   if (N > 0) {
@@ -600,7 +697,26 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
   const bool vec4 = (d % 4 == 0) && aligned16(codes) && aligned16(Wr) && aligned16(c->dcodes_own) && aligned16(q.slab);
   const double Nd = (double)N * d;
   const float k = (float)(2.0 * reg_param / Nd);
-  {
+  // energies + loss terms (+ the relation gradient's chunk partials when the rows fit a wave's registers)
+  static const int fused_env = getenv("RGCN_DEC_FUSED") ? atoi(getenv("RGCN_DEC_FUSED")) : 1;
+  const int nvec_e = vec4 ? d / 4 : d;
+  const bool fused = fused_env != 0 && nvec_e <= 256;
+  if (fused) {
+    const int T = nvec_e <= 64 ? 1 : (nvec_e <= 128 ? 2 : 4);
+    const size_t lds = ((size_t)4 * d + 8) * sizeof(float);
+    ProfScope ps(c, "dec_energy_rel", 12.0 * N * d + 20.0 * N + 4.0 * q.max_chunks * d, 9.0 * N * d);
+#define RGCN_LAUNCH_ER(VEC, TT)                                                                                    \
+  hipLaunchKernelGGL((k_dec_energy_rel<VEC, TT>), dim3(q.max_chunks), dim3(256), lds, c->stream, codes, Wr, q.X, Y, \
+                     q.permr, q.rel_ptr, q.chunk_ptr, N, R, d, q.dx, q.loss_part, q.slab)
+    if (vec4) {
+      if (T == 1) RGCN_LAUNCH_ER(4, 1); else if (T == 2) RGCN_LAUNCH_ER(4, 2); else RGCN_LAUNCH_ER(4, 4);
+    } else {
+      if (T == 1) RGCN_LAUNCH_ER(1, 1); else if (T == 2) RGCN_LAUNCH_ER(1, 2); else RGCN_LAUNCH_ER(1, 4);
+    }
+#undef RGCN_LAUNCH_ER
+    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.max_chunks, N, d, reg_param,
+                       q.loss);
+  } else {
     ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d);
     if (vec4)
       hipLaunchKernelGGL((k_dec_energy<4>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
@@ -639,8 +755,11 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
     // beside the entity gradient and the encoder's backward pass (the caller joins it: stream_join(c, 2))
     StreamScope side(c, 2);
-    ProfScope ps(c, "dec_relation_grad", 8.0 * N * d + 8.0 * R * d, 3.0 * N * d);
-    if (vec4)
+    ProfScope ps(c, "dec_relation_grad", fused ? 4.0 * q.max_chunks * d + 8.0 * R * d : 8.0 * N * d + 8.0 * R * d,
+                 fused ? 0.0 : 3.0 * N * d);
+    if (fused) {
+      // the chunk partials are already in the slab (k_dec_energy_rel)
+    } else if (vec4)
       hipLaunchKernelGGL((k_dec_rel_partial<4>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
                          q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
     else

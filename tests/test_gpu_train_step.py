@@ -32,7 +32,9 @@ def decoder_batch(rng, triples, V, neg_rate=3, hub=None):
 
 
 @pytest.mark.parametrize("V,R,d,nb,E,hub", [(60, 7, 20, 4, 200, None), (120, 9, 40, 8, 600, 5),
-                                            (50, 5, 9, 3, 100, None)])
+                                            (50, 5, 9, 3, 100, None),
+                                            (40, 5, 258, 86, 100, None),     # rows too wide for the fused energy + relation kernel
+                                            (40, 5, 520, 104, 150, 3)])      # three register tiles per lane (T = 4)
 def test_device_decoder_matches_oracle(native, V, R, d, nb, E, hub):
     L = 2
     params, triples, masks, _ = make_case(V, R, d, L, "block", nb, E, seed=E)
