@@ -255,6 +255,30 @@ def neighborhood_sampler_cases():
     return cases
 
 
+def io_cases(m_io, tmpdir):
+    """The reference's reader (common/io.py) on the shipped data files -- on COPIES: it opens files 'r+', and the
+    reference tree is not to be opened for writing.  Recorded: shapes and SHA-256 of the int32 triple arrays."""
+    import hashlib
+    import shutil
+    data = "/root/reference/data"
+    out = {}
+    for dataset, parts in (("Toy", ("train", "valid", "test")), ("FB-Toutanova", ("valid", "test")),
+                           ("wn18", ("valid", "test")), ("FB15k", ("valid",))):
+        dst = os.path.join(tmpdir, dataset)
+        os.makedirs(dst, exist_ok=True)
+        for f in ["entities.dict", "relations.dict"] + [p_ + ".txt" for p_ in parts]:
+            shutil.copyfile(os.path.join(data, dataset, f), os.path.join(dst, f))
+        ent = m_io.read_dictionary(os.path.join(dst, "entities.dict"))
+        rel = m_io.read_dictionary(os.path.join(dst, "relations.dict"))
+        rec = {"entities": len(ent), "relations": len(rel), "parts": {}}
+        for p_ in parts:
+            t = np.array(m_io.read_triplets_as_list(os.path.join(dst, p_ + ".txt"), os.path.join(dst, "entities.dict"),
+                                                    os.path.join(dst, "relations.dict")), dtype=np.int32)
+            rec["parts"][p_] = {"shape": list(t.shape), "sha256": hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()}
+        out[dataset] = rec
+    return out
+
+
 def main():
     import tempfile
     m = reference_modules()
@@ -263,6 +287,7 @@ def main():
                "scorer": scorer_cases(m), "neighborhood_sampler": neighborhood_sampler_cases()}
     for name, (extra, losses, scores) in SCENARIOS.items():
         fixture["stack"][name] = run_stack_scenario(m, extra, losses, scores, tmp)
+    fixture["io"] = io_cases(load("ref_io", REF + "/common/io.py"), tmp)
     # the reference's own settings file, as its reader parses it (values only; the file itself is not copied)
     shipped = m.settings_reader.read("/root/reference/settings/gcn_block.exp")
     import ast
