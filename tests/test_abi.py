@@ -68,3 +68,27 @@ def test_library_has_no_packed_fp32_instructions():
     from relationprediction_amd import build
     build.build()
     assert build.check_no_packed_fp32()
+
+
+def test_bench_workloads_are_backed_by_fixtures_and_fail_loudly_without_a_gpu():
+    """every bench.py workload names a graph in tests/golden/graphs.npz of the stated size and a legal geometry;
+    on a box without a GPU the bench exits non-zero with the library's error instead of falling back to anything"""
+    import importlib.util
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with np.load(os.path.join(root, "tests", "golden", "graphs.npz")) as z:
+        for name, (graph, V, R, d, L, kind, nb, E) in bench.WORKLOADS.items():
+            t = z[graph]
+            assert t.shape == (E, 3), name
+            assert t[:, [0, 2]].max() < V and t[:, 1].max() < R and t.min() >= 0, name
+            if kind == "block":
+                assert d % nb == 0 and d // nb in (1, 2, 3, 4, 5, 8), name
+    if not os.path.exists("/dev/kfd"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--cpu-steps", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "librgcn status" in r.stderr and not r.stdout.strip()
