@@ -67,3 +67,44 @@ def _chain(model):
     while c is not None:
         yield c
         c = c.next_component
+
+
+@pytest.mark.parametrize("name", ["block_2layer", "block_sd5", "basis_b2", "basis_b5_1layer"])
+def test_plugin_chain_is_a_drop_in_for_the_reference_chain(name):
+    """The SAME calls train.py makes, on this package's classes, against what the REFERENCE'S classes returned for
+    them (tests/golden/reference_model.npz, computed by the reference's own model code over a numpy stand-in for
+    TensorFlow): build_encoder / build_decoder from the same settings keys, initialize_train() under the same numpy
+    seed -> identical weights in get_weights() order; test-mode codes and the score-all-subjects / -objects matrices
+    within 1e-4."""
+    import os
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_model.npz"))
+    kind_id, V, R, d, nb, L, E, N, seed, mode = (int(x) for x in fix[name + "/config"])
+    assert mode == 0
+    kind = "block" if kind_id == 0 else "basis"
+    triples, X = fix[name + "/triples"], fix[name + "/X"]
+    enc = {'Name': 'gcn_basis', 'DropoutKeepProbability': '0.8', 'InternalEncoderDimension': str(d),
+           'NumberOfBasisFunctions': str(nb), 'NumberOfLayers': str(L), 'UseInputTransform': 'Yes',
+           'UseOutputTransform': 'No', 'AddDiagonal': 'No', 'DiagonalCoefficients': 'No', 'SkipConnections': 'None',
+           'StoreEdgeData': 'No', 'RandomInput': 'No', 'PartiallyRandomInput': 'No',
+           'Concatenation': 'Yes' if kind == 'block' else 'No', 'CodeDimension': str(d),
+           'EntityCount': V, 'RelationCount': R, 'EdgeCount': E, 'NegativeSampleRate': '10', 'GraphSplitSize': '0.5'}
+    dec = {'Name': 'bilinear-diag', 'RegularizationParameter': '0.01', 'CodeDimension': str(d),
+           'EntityCount': V, 'RelationCount': R, 'EdgeCount': E, 'NegativeSampleRate': '10'}
+    np.random.seed(seed)
+    model = model_builder.build_decoder(model_builder.build_encoder(enc, triples), dec)
+    model.preprocess(triples)
+    model.register_for_test(triples)
+    model.initialize_train()
+    weights = model.get_weights()
+    names = oracle.weight_names(kind, L)
+    assert len(weights) == len(names)
+    for i, w in enumerate(weights):
+        np.testing.assert_array_equal(w.value(), fix["%s/weight%02d" % (name, i)], err_msg=names[i])
+    subj = model.score_all_subjects(X)
+    obj = model.score_all_objects(X)
+    assert float(np.abs(subj - fix[name + "/subject_scores"]).max()) <= 1e-4
+    assert float(np.abs(obj - fix[name + "/object_scores"]).max()) <= 1e-4
+    for var, val in zip(model.get_test_input_variables(), (triples, X)):
+        var.feed(val)
+    codes = model.next_component.get_all_codes(mode='test')[0]
+    assert float(np.abs(np.asarray(codes) - fix[name + "/codes_test"]).max()) <= 1e-4
