@@ -43,8 +43,11 @@ CASES = {
     # BASELINE config 2 at full size: the real FB15k-237 minibatch graph of tests/golden/graphs.npz, d = 500, 100
     # blocks of 5x5, 2 layers; stored as fingerprints (weights and masks are regenerated from the seeds by the test)
     "fb237_block_full": ("block", 14541, 237, 500, 100, 2, 15000, 3000, 6, "intended"),
+    # BASELINE config 3 at full size: the same minibatch graph under the basis decomposition, B = 2
+    # (reference gcn_basis.py:39-88)
+    "fb237_basis_b2_full": ("basis", 14541, 237, 500, 2, 2, 15000, 3000, 12, "intended"),
 }
-FULL_SIZE = {"fb237_block_full": "fb237_minibatch"}
+FULL_SIZE = {"fb237_block_full": "fb237_minibatch", "fb237_basis_b2_full": "fb237_minibatch"}
 
 
 def fingerprint(arr, n=256, seed=0):

@@ -16,8 +16,9 @@ import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = np.load(os.path.join(HERE, "golden", "reference_model.npz"))
-FULL = "fb237_block_full"                     # stored as fingerprints; weights and masks regenerated from the seeds
-CASES = sorted({k.split("/")[0] for k in FIX.files} - {FULL})
+# BASELINE configs 2 and 3 at full size: stored as fingerprints; weights and masks regenerated from the seeds
+FULLS = ["fb237_block_full", "fb237_basis_b2_full"]
+CASES = sorted({k.split("/")[0] for k in FIX.files} - set(FULLS))
 FWD_ATOL = 1e-4            # north_star: "outputs match the reference forward pass within 1e-4 fp32"
 
 
@@ -106,19 +107,20 @@ def test_the_two_h1_readings_differ_and_the_fixture_covers_both():
     assert float(np.abs(other[-1] - c["codes_test"]).max()) > 1e-3
 
 
-# ------------------------------------------------------------------ BASELINE config 2 at full size
-def load_full():
+# ------------------------------------------------------------------ BASELINE configs 2 and 3 at full size
+def load_full(FULL):
     import helpers
     kind_id, V, R, d, nb, L, E, N, seed, mode = (int(x) for x in FIX[FULL + "/config"])
-    assert (kind_id, mode) == (0, 0)
-    names = oracle.weight_names("block", L)
+    assert mode == 0
+    kind = "block" if kind_id == 0 else "basis"
+    names = oracle.weight_names(kind, L)
     assert int(FIX[FULL + "/n_weights"]) == len(names)
     np.random.seed(seed)                                         # the reference's draws (bitwise: the small cases)
-    params = oracle.init_params(V, R, d, L, "block", nb, rng=np.random)
+    params = oracle.init_params(V, R, d, L, kind, nb, rng=np.random)
     drop = np.random.RandomState(seed)                           # the shim's dropout stream, bottom layer first
     masks = [np.floor(0.8 + drop.uniform(size=(V, d))).astype(np.uint8) for _ in range(L)]
     fp = lambda key: {f: FIX["%s/%s/%s" % (FULL, key, f)] for f in ("l2", "sum", "idx", "val")}  # noqa: E731
-    return dict(V=V, R=R, d=d, nb=nb, L=L, E=E, names=names, params=params, masks=masks,
+    return dict(V=V, R=R, d=d, nb=nb, L=L, E=E, kind=kind, names=names, params=params, masks=masks,
                 triples=helpers.load_graph("fb237_minibatch"), X=FIX[FULL + "/X"], Y=FIX[FULL + "/Y"],
                 loss=float(FIX[FULL + "/loss_train"]), fp=fp,
                 connected=[bool(FIX["%s/grad%02d_connected" % (FULL, i)]) for i in range(len(names))])
@@ -131,24 +133,25 @@ def check_codes(codes, pr, atol):
     assert abs(l2 - float(pr["l2"])) <= 1e-5 * float(pr["l2"])
 
 
-def test_full_size_oracle_equals_the_reference_dataflow():
-    """FB15k-237 gcn_block at full size (V 14,541, d 500, 100 blocks, 2 layers, the real 15,000-edge minibatch): the
-    reference's own model code computed these fingerprints; the oracle must land on them -- weights, codes in both
-    modes, loss, every gradient."""
+@pytest.mark.parametrize("full", FULLS)
+def test_full_size_oracle_equals_the_reference_dataflow(full):
+    """FB15k-237 gcn_block (100 blocks) and gcn_basis (B = 2) at full size (V 14,541, d 500, 2 layers, the real
+    15,000-edge minibatch): the reference's own model code computed these fingerprints; the oracle must land on
+    them -- weights, codes in both modes, loss, every gradient."""
     import helpers
-    c = load_full()
+    c = load_full(full)
     for i, n in enumerate(c["names"]):
         pr = c["fp"]("weight%02d" % i)
         flat = c["params"][n].ravel()
         assert np.array_equal(flat[pr["idx"]], pr["val"]), n                       # bitwise at the sampled positions
-    test = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], "block", mode="test")
+    test = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="test")
     check_codes(test[-1], c["fp"]("codes_test"), 2e-5)
-    acts = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], "block", mode="train", keep_prob=0.8,
+    acts = oracle.encoder_forward(c["params"], c["triples"], c["V"], c["L"], c["kind"], mode="train", keep_prob=0.8,
                                   dropout_masks=c["masks"])
     check_codes(acts[-1], c["fp"]("codes_train"), 2e-5)
     loss, dcodes, d_rel = oracle.distmult_loss_and_grads(acts[-1], c["params"]["W_relation"], c["X"], c["Y"], 0.01)
     assert loss == pytest.approx(c["loss"], rel=1e-5)
-    grads = oracle.encoder_backward(c["params"], c["triples"], c["V"], c["L"], "block", acts, dcodes, mode="train",
+    grads = oracle.encoder_backward(c["params"], c["triples"], c["V"], c["L"], c["kind"], acts, dcodes, mode="train",
                                     keep_prob=0.8, dropout_masks=c["masks"])
     grads["W_relation"] = d_rel
     for i, n in enumerate(c["names"]):
@@ -157,11 +160,12 @@ def test_full_size_oracle_equals_the_reference_dataflow():
 
 
 @pytest.mark.gpu
-def test_full_size_hip_path_equals_the_reference_dataflow(native):
+@pytest.mark.parametrize("full", FULLS)
+def test_full_size_hip_path_equals_the_reference_dataflow(native, full):
     """the same fingerprints through the C ABI: codes within 1e-4 absolute (north_star), loss, all gradients"""
     import helpers
-    c = load_full()
-    eng = native.Engine(c["V"], c["R"], c["d"], c["L"], "block", c["nb"], keep_prob=0.8, max_edges=c["E"])
+    c = load_full(full)
+    eng = native.Engine(c["V"], c["R"], c["d"], c["L"], c["kind"], c["nb"], keep_prob=0.8, max_edges=c["E"])
     bufs = []
     try:
         eng.set_params(c["params"])
