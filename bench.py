@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- processed edges/sec of the R-GCN encoder forward+backward (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-extra-workloads]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,11 +13,15 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   "roofline":     the dominant kernel against its gfx950 roofline (live HIP-event durations),
   "kernels":      the same accounting for every kernel of the step,
   "cpu_baseline": the CPU oracle (TF-dataflow-shaped numpy/scipy port of the reference) timed on
-                  this box's host cores on the same minibatch.
+                  this box's host cores on the same minibatch,
+  "workloads":    (N = 1, default workload) the same measurement -- value, ms/step, roofline, kernels -- for the
+                  other BASELINE.json configurations on one GPU: basis B = 2 / B = 5 (config 3), the WN18 and FB15k
+                  shapes (configs 4 and 5 on one GPU), the 38,001-edge and the 272,115-edge full graphs.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -31,9 +35,12 @@ PEAK_F32_MFMA_TFS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 
 WORKLOADS = {
-    # name: (graph fixture | None, V, R, d, L, kind, nb, E_g)   -- BASELINE.json configs[1] is the headline
+    # name: (graph fixture | "synth:..." , V, R, d, L, kind, nb, E_g)   -- BASELINE.json configs[1] is the headline
     "fb237_block": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 15000),
     "fb237_block_fullgraph": ("fb237_valid_test", 14541, 237, 500, 2, "block", 100, 38001),
+    # SURVEY 8d graph B: the FB15k-237 training graph's size (272,115 unique triples), relations and endpoints drawn
+    # from the empirical histograms of the real valid+test triples (the train split is not shipped with the reference)
+    "fb237_block_traingraph": ("synth:fb237_valid_test:272115", 14541, 237, 500, 2, "block", 100, 272115),
     "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
     # BASELINE.json configs[3]'s shape on one GPU: WN18 (V 40,943 / R 18), the 10,000 real valid+test triples as graph
     "wn18_block": ("wn18_valid_test", 40943, 18, 500, 2, "block", 100, 10000),
@@ -43,6 +50,52 @@ WORKLOADS = {
     "fb237_basis_b2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 15000),
     "fb237_basis_b5": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 5, 15000),
 }
+# measured after the headline workload in the default single-GPU run (one driver line carries all of them)
+EXTRA_WORKLOADS = ["fb237_basis_b2", "fb237_basis_b5", "wn18_block", "fb15k_block", "fb237_block_fullgraph",
+                   "fb237_block_traingraph"]
+
+
+def synthetic_from_histograms(pool, n, seed=0):
+    """n unique triples: r ~ the pool's relation histogram, s | r and o | r ~ the pool's conditional endpoint
+    histograms (SURVEY 8d 'graph B').  Relations whose empirical support cannot hold their share (|S_r| x |O_r|
+    distinct pairs) saturate; the remainder is redrawn until n unique triples exist."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    pool = np.asarray(pool, dtype=np.int64)
+    order = np.argsort(pool[:, 1], kind="stable")
+    by_rel = pool[order]
+    rels, starts, counts = np.unique(by_rel[:, 1], return_index=True, return_counts=True)
+    p_rel = counts / counts.sum()
+    V = int(pool[:, [0, 2]].max()) + 1
+    R = int(pool[:, 1].max()) + 1
+    seen = np.empty(0, dtype=np.int64)
+    for _ in range(64):
+        need = n - seen.size
+        if need <= 0:
+            break
+        m = int(need * 1.5) + 1024
+        ri = rng.choice(len(rels), size=m, p=p_rel)
+        # endpoint | relation: a uniformly chosen occurrence of that relation in the pool (= its histogram)
+        si = starts[ri] + (rng.random_sample(m) * counts[ri]).astype(np.int64)
+        oi = starts[ri] + (rng.random_sample(m) * counts[ri]).astype(np.int64)
+        key = (by_rel[si, 0] * R + rels[ri]) * V + by_rel[oi, 2]
+        seen = np.unique(np.concatenate([seen, key]))
+    if seen.size < n:
+        raise RuntimeError("the empirical histograms support only %d unique triples" % seen.size)
+    seen = seen[rng.permutation(seen.size)[:n]]
+    out = np.stack([seen // (R * V), (seen // V) % R, seen % V], axis=1)
+    return np.ascontiguousarray(out.astype(np.int32))
+
+
+def load_graph(name):
+    """graph of a workload: a fixture of tests/golden/graphs.npz (made by tests/golden/make_golden.py from the
+    reference's data files; /root/reference itself is not needed at run time) or 'synth:<pool fixture>:<n>'"""
+    import numpy as np
+    with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
+        if name.startswith("synth:"):
+            _, pool, n = name.split(":")
+            return synthetic_from_histograms(z[pool], int(n), seed=0)
+        return np.ascontiguousarray(z[name].astype(np.int32))
 
 
 def parse_args():
@@ -51,6 +104,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fb237_block", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="only the --workload line (default: the single-GPU run of the headline workload also "
+                         "measures the other BASELINE configurations into \"workloads\")")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra workload")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--hipgraph", action="store_true",
@@ -62,47 +119,70 @@ def parse_args():
     return ap.parse_args()
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+class Ranks:
+    """rank / world plumbing of one bench process (one rank per GPU under torch.distributed.run)"""
 
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+            args.gpus = self.world
+        self.rdv_path = "/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+
+
+# profile tag (csrc ProfScope name) -> HIP kernel name prefix in the rocprofv3 summaries
+KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "k_gemm_bf16x3<true, true",
+                 "gemm_self_dw": "k_gemm_bf16x3<false, false", "block_msg_fwd": "k_block_msg_fwd",
+                 "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine",
+                 "input_fwd": "k_input_fwd", "top_grad_dropout": "k_scale_dropout", "block_dw_reduce": "k_block_dw_reduce",
+                 "splitk_reduce": "k_splitk_reduce", "bias_grad_colsum": "k_colsum_part"}
+
+
+def traffic_table(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*traffic*.json,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be collected from inside the process"""
+    try:
+        named = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_%s.json" % workload)))
+        plain = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_serial_traffic.json"))) if workload == "fb237_block" else []
+        pick = (named or plain)
+        if pick:
+            return json.load(open(pick[-1]))["kernels"], os.path.relpath(pick[-1], ROOT)
+    except Exception:  # noqa: BLE001
+        pass
+    return {}, None
+
+
+def measure(workload, args, rk, steps, warmup, full):
+    """One workload on this rank's engine: timed steps (barrier + sync on both sides, max over ranks), then the
+    per-kernel passes.  full = the headline extras (fp32-MFMA reference run, CPU baseline)."""
     import numpy as np
-
-    if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
-        import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
-
     from relationprediction_amd import _native
     from relationprediction_amd.sharding import lpt_partition
-
-    graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[args.workload]
-    # real graph structure committed as a fixture (tests/golden/make_golden.py reads the reference's
-    # data files with the reference's formats; /root/reference itself is not needed at run time)
-    with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
-        triples = np.ascontiguousarray(z[graph_name].astype(np.int32))
-        # a second minibatch of the same size so that consecutive steps see different graphs (as in
-        # training, where t_func samples a new one every step): steps alternate A, B, A, B ...
-        pool = z["fb237_valid_test"].astype(np.int32) if graph_name == "fb237_minibatch" else triples
-    rs = np.random.RandomState(7)
-    triples_b = np.ascontiguousarray(pool[rs.choice(pool.shape[0], size=triples.shape[0], replace=False)]) \
-        if pool.shape[0] >= triples.shape[0] else triples
-    assert triples.shape[0] == E_g
     from relationprediction_amd.common.shared_functions import init_encoder_params
+
+    rank, world = rk.rank, rk.world
+    graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[workload]
+    triples = load_graph(graph_name)
+    assert triples.shape[0] == E_g
+    # a second minibatch of the same size so that consecutive steps see different graphs (as in training, where
+    # t_func samples a new one every step): steps alternate A, B, A, B ...
+    if graph_name == "fb237_minibatch":
+        pool = load_graph("fb237_valid_test")
+        triples_b = np.ascontiguousarray(pool[np.random.RandomState(7).choice(pool.shape[0], size=E_g, replace=False)])
+    else:
+        triples_b = np.ascontiguousarray(triples[np.random.RandomState(7).permutation(E_g)])
     params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
     dcodes = (np.random.RandomState(2).randn(V, d) * 1e-3).astype(np.float32)
 
     # RGCN_BENCH_SHARE_GPU=1 (tests only, with RGCN_RCCL_LIBRARY pointing at the shared-memory collective of
     # tests/collective_double): every rank on device 0, to run the multi-process path on a one-GPU box
-    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" else local_rank
+    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" else rk.local_rank
     eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
                          device=device, rank=rank, world=world)
     eng.set_params(params)
-    rdv_path = None
     if world > 1:
         # One rank per GPU (launched by torch.distributed.run, which only provides the environment).
         # The process keeps ONE ROCm stack: no torch import here; the 128-byte RCCL id travels through a
@@ -110,9 +190,8 @@ def main():
         # the library's own RCCL communicator.
         owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
         eng.set_relation_owner(owner)
-        rdv_path = "/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
         from relationprediction_amd.sharding import share_unique_id
-        uid = share_unique_id(rank, rdv_path, _native.Engine.comm_unique_id)
+        uid = share_unique_id(rank, rk.rdv_path, _native.Engine.comm_unique_id)
         eng.comm_init(uid)
     comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
 
@@ -127,9 +206,7 @@ def main():
     tri_dev_b = eng.to_device(triples_b)
     dc_dev = eng.to_device(dcodes)
     graphs = [tri_dev, tri_dev_b]
-    # the side-stream graph preparation is exercised and verified on one GPU only (the multi-GPU path cannot be
-    # run on the 1-GPU development box): sharded runs prepare the graph in line
-    pipeline = os.environ.get("RGCN_BENCH_PREFETCH", "1") != "0" and world == 1
+    pipeline = os.environ.get("RGCN_BENCH_PREFETCH", "1") != "0"
 
     def barrier():
         eng.sync()
@@ -146,10 +223,10 @@ def main():
                 eng.prefetch_graph_device(graphs[(i + 1) % 2], E_g)
 
     eng.set_gemm_mode(args.gemm_mode)
-    run(args.warmup, 1000)
+    run(warmup, 1000)
     use_graph = args.hipgraph and world == 1 and pipeline
     if use_graph:
-        if args.steps % 2:
+        if steps % 2:
             sys.exit("--hipgraph: --steps must be even (one launch = two steps)")
         # steady state of the pipelined loop as ONE graph: step on A beside the preparation of B, then the reverse
         eng.prefetch_graph_device(graphs[0], E_g)
@@ -170,22 +247,20 @@ def main():
     barrier()
     t0 = time.perf_counter()
     eng.timer_start()
-    run(args.steps, 2000)
+    run(steps, 2000)
     gpu_ms = eng.timer_stop()
     eng.sync()
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
         wall = float(allgather_scalar(wall).max())     # max over ranks
-        if rank == 0 and rdv_path and os.path.exists(rdv_path):
-            os.remove(rdv_path)
-    ms_per_step = wall * 1e3 / args.steps
-    value = E_g * args.steps / wall
+    ms_per_step = wall * 1e3 / steps
+    value = E_g * steps / wall
 
     # ---- the same step with the dense contractions on the fp32 MFMA (mode 0), for reference
     fp32_ref = None
-    if args.gemm_mode != 0:
-        n2 = max(10, args.steps // 2)
+    if full and args.gemm_mode != 0:
+        n2 = max(10, steps // 2)
         eng.set_gemm_mode(0)
         run(3, 3000)
         barrier()
@@ -208,13 +283,13 @@ def main():
     if not args.no_kernel_profile:
         eng.profile_reset()
         eng.profile_enable(True)
-        run(args.steps, 2000)
+        run(steps, 2000)
         in_pipeline = {p["name"]: p["total_ms"] / max(p["calls"], 1) for p in eng.profile()}
         eng.profile_enable(False)
         eng.set_overlap(False)
         eng.profile_reset()
         eng.profile_enable(True)
-        run(args.steps, 2000, pipeline=False)
+        run(steps, 2000, pipeline=False)
         prof = eng.profile()
         eng.profile_enable(False)
         eng.set_overlap(os.environ.get("RGCN_STREAMS", "1") != "0")
@@ -234,39 +309,28 @@ def main():
                 ach, peak, unit = terms * fl / sec / 1e12, mfma_peak, "TFLOP/s"
             else:
                 ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-            kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / args.steps,
+            kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / steps,
                             "avg_us": round(avg_ms * 1e3, 2),
                             "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
-                            "ms_per_step": round(p["total_ms"] / args.steps, 4),
+                            "ms_per_step": round(p["total_ms"] / steps, 4),
                             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                             "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
             if bound == "mfma":
                 kernels[-1]["mfma_dtype"] = "bf16 (x%d exact operand split of fp32)" % terms if args.gemm_mode else "f32"
                 kernels[-1]["executed_flops"] = terms * fl
                 kernels[-1]["fp32_equivalent_tflops"] = round(fl / sec / 1e12, 2)
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/*_traffic.json, FETCH_SIZE doubled per MI355X_MICROARCH.md): not collectable live
-        traffic = {}
-        try:
-            import glob
-            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-            if tj and args.workload == "fb237_block":
-                traffic = json.load(open(tj[-1]))["kernels"]
-        except Exception:  # noqa: BLE001
-            traffic = {}
-        gk = "k_gemm_bf16x3" if args.gemm_mode else "k_gemm_f32"
-        alias = {"gemm_self_fwd": gk + "<true, false", "gemm_self_dh": gk + "<true, true",
-                 "gemm_self_dw": gk + "<false, false", "block_msg_fwd": "k_block_msg_fwd",
-                 "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine"}
+        traffic, traffic_src = traffic_table(workload)
         for k in kernels:
-            pref = alias.get(k["kernel"])
+            pref = KERNEL_OF_TAG.get(k["kernel"])
+            if pref and pref.startswith("k_gemm") and args.gemm_mode == 0:
+                pref = None          # the PMC passes ran the default arithmetic
             k["traffic"] = next((round(v) for n, v in traffic.items() if pref and n.startswith(pref)), None)
         kernels.sort(key=lambda k: -k["ms_per_step"])
         if kernels:
             k = kernels[0]
             roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                        "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_us": k["avg_us"],
-                        "avg_us_in_pipeline": k["avg_us_in_pipeline"],
+                        "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "traffic_source": traffic_src,
+                        "avg_us": k["avg_us"], "avg_us_in_pipeline": k["avg_us_in_pipeline"],
                         "note": "exclusive duration (overlap off); in the pipelined step it co-runs with HBM-bound kernels",
                         "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
             for extra in ("mfma_dtype", "executed_flops", "fp32_equivalent_tflops"):
@@ -285,10 +349,12 @@ def main():
             Wl = 4.0 * (2 * d * nb * d + 2 * R * nb + d * d)
         compulsory = L * (2 * I + 5 * P + 3 * Wl) + 4 * P          # B_alg of one encoder step
         staged = sum(k["alg_bytes"] * k["launches_per_step"] for k in kernels)
+        measured = sum(k["traffic"] * k["launches_per_step"] for k in kernels if k["traffic"])
         sf = sum(k["alg_flops"] * k["launches_per_step"] for k in kernels)
         sec = ms_per_step * 1e-3
         ceiling = compulsory / (PEAK_HBM_GBS * 1e9) + sf / (PEAK_F32_MFMA_TFS * 1e12)
         step_roofline = {"compulsory_bytes_per_step": compulsory, "kernel_sum_bytes_per_step": staged,
+                         "pmc_bytes_per_step": measured or None,
                          "alg_flops_per_step": sf,
                          "hbm_gbs": round(compulsory / sec / 1e9, 1),
                          "hbm_frac": round(compulsory / sec / 1e9 / PEAK_HBM_GBS, 4),
@@ -299,13 +365,14 @@ def main():
                          "frac_of_serial_ceiling": round(ceiling / sec, 4),
                          "note": "whole step on this rank over the measured step time.  compulsory = SURVEY 8d's "
                                  "L*(2I+5P+3W)+4P (each distinct input read once, each output written once); "
-                                 "kernel_sum = what the two-stage kernels move by design (messages staged through "
-                                 "HBM / L2 between the relation-major and the row-major stage); ceiling = "
+                                 "kernel_sum = what the kernels move by design (messages staged through "
+                                 "HBM / L2 between the relation-major and the row-major stage); pmc = rocprofv3 "
+                                 "FETCH/WRITE_SIZE bytes of the committed PMC passes x launches; ceiling = "
                                  "compulsory / 8 TB/s + fp32 flops / 157.3 TF with nothing overlapped"}
 
     # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
+    if full and rank == 0 and world == 1 and args.cpu_steps > 0:
         import oracle  # test infrastructure; used here ONLY as the timed CPU baseline
         masks = [(np.random.RandomState(3 + l).rand(V, d) < 0.8).astype(np.uint8) for l in range(L)]
         oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)  # warm-up
@@ -320,20 +387,26 @@ def main():
                "threads": "BLAS threads = host cores for the dense products (self-loop, basis); the sparse incidence "
                           "products, gathers and batched 5x5 products of the TF-shaped dataflow run on one thread",
                "sample": "%d steps of the same %s minibatch (E_g=%d) through oracle.encoder_step "
-                         "(numpy/scipy fp32, TF-dataflow-shaped), median" % (args.cpu_steps, args.workload, E_g)}
+                         "(numpy/scipy fp32, TF-dataflow-shaped), median" % (args.cpu_steps, workload, E_g)}
 
+    out = None
     if rank == 0:
+        dataset = {"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(workload[:4], "FB15k-237")
+        if graph_name.startswith("synth:"):
+            data = ("synthetic graph: %d unique triples, relation and endpoint-given-relation histograms of the real "
+                    "FB15k-237 valid+test triples (SURVEY 8d graph B; the train split is not shipped), " % E_g)
+        else:
+            data = "real graph structure (fixture %s of tests/golden/graphs.npz, %d edges; SURVEY 8d), " % (graph_name, E_g)
         out = {
-            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % ({"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(args.workload[:4], "FB15k-237"), kind),
-            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % (dataset, kind),
+            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == 0 else
                      "f32 (dense contractions: fp32 operands split exactly into 3 bf16, %d of 9 partial products on the "
                      "bf16 matrix cores, fp32 accumulation; error vs float64 equal to the fp32 MFMA's)" % args.gemm_mode,
-            "data": "real graph structure (fixture %s of tests/golden/graphs.npz, %d edges; SURVEY 8d), "
-                    "reference-distribution random-init weights, synthetic upstream gradient" % (graph_name, E_g),
-            "config": {"workload": args.workload, "entities": V, "relations": R, "dim": d, "layers": L,
+            "data": data + "reference-distribution random-init weights, synthetic upstream gradient",
+            "config": {"workload": workload, "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
                        "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
                                 "two alternating minibatches, next graph's prep pipelined on a side stream"
@@ -341,7 +414,7 @@ def main():
                                if pipeline else
                                "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
                        "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
-            "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
+            "gpu_event_ms_per_step": round(gpu_ms / steps, 4),
             "message_edges_per_s": round(2 * L * value, 1),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,
@@ -354,6 +427,28 @@ def main():
     if comm_buf is not None:
         comm_buf.free()
     eng.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    rk = Ranks(args)
+    if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
+        import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
+
+    out = measure(args.workload, args, rk, args.steps, args.warmup, full=True)
+    extras = []
+    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
+        for w in EXTRA_WORKLOADS:
+            o = measure(w, args, rk, args.extra_steps, min(args.warmup, 5), full=False)
+            for drop in ("cpu_baseline", "fp32_mfma_reference", "higher_is_better", "vs_baseline"):
+                o.pop(drop, None)
+            extras.append(o)
+    if rk.rank == 0:
+        out["workloads"] = extras
+    if rk.world > 1 and rk.rank == 0 and os.path.exists(rk.rdv_path):
+        os.remove(rk.rdv_path)
+
     # The ONE JSON line goes out last: every rank first shuts its engine down and pushes out whatever C-level
     # libraries (RCCL's debug facility writes to stdout) left in the stdio buffer, and says so through a marker
     # file next to the rendezvous file; rank 0 prints when all ranks have done that (or after a minute).
@@ -363,19 +458,19 @@ def main():
     except OSError:
         pass
     sys.stdout.flush()
-    if world > 1:
-        marker = "%s.done" % ("/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
-        if rank != 0:
-            open("%s.%d" % (marker, rank), "w").close()
+    if rk.world > 1:
+        marker = "%s.done" % rk.rdv_path
+        if rk.rank != 0:
+            open("%s.%d" % (marker, rk.rank), "w").close()
         else:
             deadline = time.time() + 60
-            others = ["%s.%d" % (marker, r) for r in range(1, world)]
+            others = ["%s.%d" % (marker, r) for r in range(1, rk.world)]
             while time.time() < deadline and not all(os.path.exists(p) for p in others):
                 time.sleep(0.02)
             for p in others:
                 if os.path.exists(p):
                     os.remove(p)
-    if rank == 0:
+    if rk.rank == 0:
         print(json.dumps(out), flush=True)
 
 

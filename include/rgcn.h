@@ -247,7 +247,11 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, in
  * rgcn_set_graph_device) on a side stream into a second buffer set while the step already queued
  * keeps running.  A later rgcn_step_device with the same (pointer, num_edges) adopts them instead of
  * rebuilding.  Call it AFTER queueing the current step.  The reference has no counterpart: its graph
- * arrives through feed_dict at session.run (optimize.py:81-88). */
+ * arrives through feed_dict at session.run (optimize.py:81-88).
+ * Contract: the triple buffer must not change between this call and the step that adopts the preparation.
+ * Writing it through rgcn_copy_to_device* or freeing it through rgcn_device_free drops the preparation (the
+ * step then rebuilds in line); writes the library cannot see (the caller's own kernels / copies) are the
+ * caller's responsibility -- call rgcn_prefetch_graph_device again after them. */
 rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev_next, int64_t num_edges);
 
 /* ---- hipGraph capture of whole steps (BASELINE config 5: "hipGraph-captured train step") -------------

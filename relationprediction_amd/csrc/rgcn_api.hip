@@ -130,12 +130,17 @@ static int auto_split_k(int M, int N, int K) {
   return s;
 }
 
-static rgcn_status check_dev_flag(rgcn_ctx* c) {
+// main_only: wait for the main stream alone (everything a finished step depends on was joined into it); the
+// graph preparation of the NEXT minibatch, running on the prefetch stream, is left alone and its id check
+// surfaces at the next synchronising call.
+static rgcn_status check_dev_flag(rgcn_ctx* c, bool main_only = false) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   int32_t flag = 0;
-  if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
-  for (int k = 0; k < kAuxStreams; ++k)
-    if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
+  if (!main_only) {
+    if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
+    for (int k = 0; k < kAuxStreams; ++k)
+      if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
+  }
   RGCN_HIP(c, hipMemcpyAsync(&flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   if (flag) {
@@ -144,6 +149,17 @@ static rgcn_status check_dev_flag(rgcn_ctx* c) {
                                    "relation id outside [0,RelationCount)");
   }
   return RGCN_OK;
+}
+
+// A caller that rewrites (or frees) the triple buffer a prefetched graph was prepared from makes that
+// preparation stale: drop it, the next step rebuilds in line.
+static void invalidate_prefetch_of(rgcn_ctx* c, const void* dev, size_t bytes) {
+  for (GraphBufs* g : {&c->g, &c->g_alt}) {
+    if (!g->pf_valid || !g->pf_tri) continue;
+    const char* t = reinterpret_cast<const char*>(g->pf_tri);
+    const char* lo = reinterpret_cast<const char*>(dev);
+    if (t + sizeof(int32_t) * 3 * (size_t)g->pf_E > lo && t < lo + (bytes ? bytes : 1)) g->pf_valid = false;
+  }
 }
 
 static rgcn_status to_host(rgcn_ctx* c, void* host, const void* dev, size_t bytes) {
@@ -825,7 +841,7 @@ rgcn_status rgcn_get_loss(rgcn_ctx* c, double* loss) {
   RGCN_NEED(c);
   if (!loss) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
   if (!c->dec.loss_valid) RGCN_FAIL(c, RGCN_ERR_STATE, "no decoder pass has run");
-  RGCN_TRY(check_dev_flag(c));
+  RGCN_TRY(check_dev_flag(c, /*main_only=*/true));
   return to_host(c, loss, c->dec.loss, sizeof(double));
 }
 
@@ -1125,12 +1141,17 @@ rgcn_status rgcn_device_free(rgcn_ctx* c, void* dev) {
   RGCN_NEED(c);
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
-  if (dev) RGCN_HIP(c, hipFree(dev));
+  if (dev) {
+    invalidate_prefetch_of(c, dev, 1);
+    if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));   // a prefetch may still be reading it
+    RGCN_HIP(c, hipFree(dev));
+  }
   return RGCN_OK;
 }
 rgcn_status rgcn_copy_to_device(rgcn_ctx* c, void* dev, const void* host, int64_t bytes) {
   RGCN_NEED(c);
   if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  invalidate_prefetch_of(c, dev, (size_t)bytes);
   return to_dev(c, dev, host, (size_t)bytes);
 }
 rgcn_status rgcn_copy_to_device_async(rgcn_ctx* c, void* dev, const void* host, int64_t bytes,
@@ -1139,6 +1160,7 @@ rgcn_status rgcn_copy_to_device_async(rgcn_ctx* c, void* dev, const void* host, 
   if (!dev || !host || bytes < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
   if (bytes == 0) return RGCN_OK;
+  invalidate_prefetch_of(c, dev, (size_t)bytes);
   hipStream_t st = on_prefetch_stream ? c->pf_stream : c->main_stream;
   if ((size_t)bytes > rgcn_ctx::kStageBytes) {      // too large for a staging slot: ordered on `st`, host waits
     RGCN_HIP(c, hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, st));

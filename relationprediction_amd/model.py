@@ -13,6 +13,8 @@ defines it and otherwise delegated inward (`__delegate__`), or run locally AND d
   * `backward()` replaces `tf.gradients(loss, weights)` (code/optimization/abstract.py:117-118): it
     returns the gradient list aligned with `get_weights()`.
 """
+import os
+
 import numpy as np
 
 
@@ -91,15 +93,20 @@ class Model(object):
 
     # ---- checkpoint: weight list in get_weights() order (reference: tf.train.Saver, model.py:30-39)
     def save(self, save_path):
+        """`.npz` of the weight list (NOT interchangeable with the reference's tf.train.Saver checkpoints):
+        key = "<position in get_weights(), 4 digits>_<name>"."""
         weights = self.get_weights()
         print("saving...")
+        parent = os.path.dirname(save_path)
+        if parent:
+            os.makedirs(parent, exist_ok=True)      # e.g. ExperimentName = models/GcnBlock
         np.savez(save_path + "-" + str(self.save_iter) + ".npz",
-                 **{"%02d_%s" % (i, w.name): w.value() for i, w in enumerate(weights)})
+                 **{"%04d_%s" % (i, w.name): w.value() for i, w in enumerate(weights)})
         self.save_iter += 1
 
     def load(self, npz_path):
         with np.load(npz_path) as z:
-            stored = [z[k] for k in sorted(z.files)]
+            stored = [z[k] for k in sorted(z.files, key=lambda k: int(k.split("_", 1)[0]))]
         weights = self.get_weights()
         if len(stored) != len(weights):
             raise ValueError("checkpoint has %d tensors, model has %d" % (len(stored), len(weights)))

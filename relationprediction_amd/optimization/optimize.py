@@ -153,72 +153,97 @@ class AdditionalOp(IOptimizer):                # TF update ops of variational la
     op = None
 
 
-class ModelSaver(IOptimizer):                  # shared/algorithms.py:62-80
+class PostStepHook(IOptimizer):
+    """A component that only acts AFTER a step.  The reference's reporting / saving / stopping components all share
+    one control flow (shared/algorithms.py:62-159): let the wrapped component see the loss first, give way to its
+    'stop', then do the own thing.  Here that flow exists once; a hook states a period (`period_attr` names the
+    parameter the settings provide, `phase` = the iteration residue it fires on) and a `fire(loss)` that may
+    return 'stop'."""
+    period_attr = None
+    phase = 0
+
+    def observe(self, loss):
+        """every iteration, before the periodic part"""
+
+    def fire(self, loss):
+        raise NotImplementedError
+
+    def postprocess(self, loss):
+        verdict = self.next_component.postprocess(loss)
+        if verdict == 'stop':
+            return verdict
+        self.observe(loss)
+        if self.iteration % getattr(self, self.period_attr) == self.phase and self.fire(loss) == 'stop':
+            return 'stop'
+        return verdict
+
+
+class ModelSaver(PostStepHook):                # shared/algorithms.py:62-80
     model_path = None
     save_function = None
     save_every_n = 1
+    period_attr = 'save_every_n'
 
     def valid(self):
-        return self.model_path is not None and self.save_function is not None
+        return None not in (self.model_path, self.save_function)
 
-    def postprocess(self, loss):
-        value_of_next = self.next_component.postprocess(loss)
-        if value_of_next == 'stop':
-            return 'stop'
-        if self.iteration % self.save_every_n == 0:
-            self.save_function(self.model_path)
-        return value_of_next
+    def fire(self, loss):
+        self.save_function(self.model_path)
 
 
-class TrainLossReporter(IOptimizer):           # shared/algorithms.py:83-115
+class TrainLossReporter(PostStepHook):         # shared/algorithms.py:83-115
     evaluate_every_n = 1
-    cummulative_loss = 0
+    period_attr = 'evaluate_every_n'
+    phase = 1                                   # iteration k*n + 1 closes the window (k-1)*n+1 .. k*n (n = 1: never,
+                                                # as in the reference: x % 1 is never 1)
+
+    def __init__(self, next_component, parameters):
+        PostStepHook.__init__(self, next_component, parameters)
+        self._window = 0.0
+
+    def observe(self, loss):
+        self._window += loss
 
     def postprocess(self, loss):
-        value_of_next = self.next_component.postprocess(loss)
-        if value_of_next == 'stop':
-            return 'stop'
-        self.cummulative_loss += loss
-        if self.iteration == 1:
-            self.cummulative_loss = 0
-            print("Initial loss: " + str(loss))
-            return value_of_next
-        if self.iteration % self.evaluate_every_n == 1:
-            average_loss = self.cummulative_loss / float(self.evaluate_every_n)
-            self.cummulative_loss = 0
-            print("Average train loss for iteration " + str(self.iteration - self.evaluate_every_n) + "-"
-                  + str(self.iteration - 1) + ": " + str(average_loss))
-        return value_of_next
+        if self.iteration == 1:                 # the first loss is reported on its own and opens no window
+            verdict = self.next_component.postprocess(loss)
+            if verdict != 'stop':
+                print("Initial loss: " + str(loss))
+            return verdict
+        return PostStepHook.postprocess(self, loss)
+
+    def fire(self, loss):
+        n = self.evaluate_every_n
+        mean, self._window = self._window / float(n), 0.0
+        print("Average train loss for iteration %s-%s: %s" % (self.iteration - n, self.iteration - 1, mean))
 
 
-class EarlyStopper(IOptimizer):                # shared/algorithms.py:118-159
+class EarlyStopper(PostStepHook):              # shared/algorithms.py:118-159
     criteria = None
     evaluate_every_n = 1
-    previous_validation_score = None
     burnin = 0
     scoring_function = None
     comparator = None
+    period_attr = 'evaluate_every_n'
+
+    def __init__(self, next_component, parameters):
+        PostStepHook.__init__(self, next_component, parameters)
+        self._last_score = None
 
     def valid(self):
-        if self.criteria != 'score_validation_data':
-            return False
-        return self.scoring_function is not None and self.comparator is not None and self.evaluate_every_n is not None
+        return self.criteria == 'score_validation_data' and \
+            None not in (self.scoring_function, self.comparator, self.evaluate_every_n)
 
-    def postprocess(self, loss):
-        value_of_next = self.next_component.postprocess(loss)
-        if value_of_next == 'stop':
+    def fire(self, loss):
+        score = self.scoring_function(self.validation_data)
+        print("Tested validation score at iteration %s. Result: %s" % (self.iteration, score))
+        worse = self._last_score is not None and not self.comparator(score, self._last_score)
+        if worse and self.iteration > self.burnin:
+            print("Stopping criterion reached.")
             return 'stop'
-        if self.iteration % self.evaluate_every_n == 0:
-            validation_score = self.scoring_function(self.validation_data)
-            print("Tested validation score at iteration " + str(self.iteration) + ". Result: " + str(validation_score))
-            if self.previous_validation_score is not None and \
-                    not self.comparator(validation_score, self.previous_validation_score):
-                if self.iteration > self.burnin:
-                    print("Stopping criterion reached.")
-                    return 'stop'
-                print("Ignoring criterion while in burn-in phase.")
-            self.previous_validation_score = validation_score
-        return value_of_next
+        if worse:
+            print("Ignoring criterion while in burn-in phase.")
+        self._last_score = score
 
 
 COMPONENTS = {c.__name__: c for c in (IterationCounter, Minibatches, SampleTransformer, GradientClipping, Adam,

@@ -19,12 +19,16 @@ from .optimization.optimize import build_hip
 
 
 def load_dataset(dataset, metric='MRR'):
+    """code/train.py:21-47.  Only the MRR protocol is built (the reference's Accuracy branch reads the
+    *_accuracy.txt files and scores with compute_accuracy_scores): anything else is refused HERE, at start-up,
+    not at the first early-stopping check thousands of iterations in."""
+    if metric != 'MRR':
+        raise NotImplementedError("Evaluation.Metric = %r: only 'MRR' is implemented" % (metric,))
     relations_path = dataset + '/relations.dict'
     entities_path = dataset + '/entities.dict'
-    suffix = '_accuracy' if metric == 'Accuracy' else ''
     splits = {}
     for name in ('train', 'valid', 'test'):
-        path = dataset + '/' + name + (suffix if name != 'train' else '') + '.txt'
+        path = dataset + '/' + name + '.txt'
         splits[name] = np.array(io.read_triplets_as_list(path, entities_path, relations_path), dtype=np.int32)
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
@@ -40,6 +44,11 @@ def make_transform(train_triplets, general_settings, encoder, device_negatives=F
     ns = auxilliaries.NegativeSampler(int(general_settings['NegativeSampleRate']), general_settings['EntityCount'])
     ns.set_known_positives(train_triplets)
     use_sampler = 'GraphBatchSize' in general_settings
+    if use_sampler and int(general_settings['GraphBatchSize']) > len(train_triplets):
+        # the reference's sampler runs out of edges and dies on NaN probabilities (train.py:173-178)
+        raise ValueError("General.GraphBatchSize = %d exceeds the %d training edges (EdgeCount): remove the key to "
+                         "train on the whole graph, or lower it" % (int(general_settings['GraphBatchSize']),
+                                                                    len(train_triplets)))
     local = threading.local()            # the native sampler keeps per-sample state: one per thread
 
     def seeded(x, seed):

@@ -81,13 +81,16 @@ def test_bench_workloads_are_backed_by_fixtures_and_fail_loudly_without_a_gpu():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    with np.load(os.path.join(root, "tests", "golden", "graphs.npz")) as z:
-        for name, (graph, V, R, d, L, kind, nb, E) in bench.WORKLOADS.items():
-            t = z[graph]
-            assert t.shape == (E, 3), name
-            assert t[:, [0, 2]].max() < V and t[:, 1].max() < R and t.min() >= 0, name
-            if kind == "block":
-                assert d % nb == 0 and d // nb in (1, 2, 3, 4, 5, 8), name
+    for name, (graph, V, R, d, L, kind, nb, E) in bench.WORKLOADS.items():
+        t = bench.load_graph(graph)        # a fixture of tests/golden/graphs.npz, or drawn from one's histograms
+        assert t.shape == (E, 3) and t.dtype == np.int32, name
+        assert t[:, [0, 2]].max() < V and t[:, 1].max() < R and t.min() >= 0, name
+        if graph.startswith("synth:"):
+            assert len(np.unique(t, axis=0)) == E, name
+            assert np.array_equal(t, bench.load_graph(graph)), name      # deterministic
+        if kind == "block":
+            assert d % nb == 0 and d // nb in (1, 2, 3, 4, 5, 8), name
+    assert set(bench.EXTRA_WORKLOADS) <= set(bench.WORKLOADS)
     if not os.path.exists("/dev/kfd"):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--cpu-steps", "0"],
                            capture_output=True, text=True, timeout=300)

@@ -298,3 +298,40 @@ def test_minibatch_transform_semantics():
             assert (block[:, 1] == X[:nb, 1]).all() and (same_s | same_o).all()
         again = t_func.seeded(triples, 7)
         assert np.array_equal(again[0], graph_split) and np.array_equal(again[1], X)
+    # H7: more edges asked for than the graph has (Toy under the shipped gcn_block.exp) is refused at start-up,
+    # by name, instead of dying in the sampler at the first batch
+    with pytest.raises(ValueError, match="GraphBatchSize"):
+        train.make_transform(triples, {'NegativeSampleRate': '3', 'EntityCount': V, 'GraphSplitSize': '0.5',
+                                       'GraphBatchSize': str(len(triples) + 1)}, GraphEncoder())
+
+
+def test_unsupported_metric_and_checkpoint_directory(tmp_path):
+    """Evaluation.Metric other than MRR is refused when the dataset is loaded (the reference switches to its
+    accuracy files there); Model.save creates the checkpoint's directory and load restores by stored position"""
+    from relationprediction_amd import train
+    with pytest.raises(NotImplementedError, match="MRR"):
+        train.load_dataset(str(tmp_path), metric='Accuracy')
+    from relationprediction_amd.model import Model
+
+    class W(object):
+        def __init__(self, name, v):
+            self.name, self.v = name, v
+
+        def value(self):
+            return self.v
+
+        def assign(self, v):
+            self.v = v
+
+    class M(Model):
+        def __init__(self, ws):
+            self.ws, self.save_iter = ws, 0
+
+        def get_weights(self):
+            return self.ws
+    ws = [W("w%d" % i, np.full(2, float(i), np.float32)) for i in range(120)]       # more than 100 tensors
+    m = M(ws)
+    m.save(str(tmp_path / "models" / "Run"))
+    m2 = M([W("w%d" % i, np.zeros(2, np.float32)) for i in range(120)])
+    m2.load(str(tmp_path / "models" / "Run-0.npz"))
+    assert all(np.array_equal(a.v, b.v) for a, b in zip(m.ws, m2.ws))

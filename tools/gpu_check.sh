@@ -1,12 +1,28 @@
 #!/bin/bash
-# One GPU-box visit: parity tests (survive a crashing test via an xdist worker), then a short bench.
+# One GPU-box visit: parity tests (survive a crashing test via an xdist worker), then the default bench
+# (headline workload + the "workloads" array).  Usage: tools/gpu_check.sh [tag] [extra pytest args]
+TAG=${1:-check}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2
-rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" 
-timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 600 -p no:cacheprovider "$@" > gpurun_out/pytest_gpu.log 2>&1
+rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing"
+timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 600 -p no:cacheprovider "$@" > gpurun_out/pytest_gpu_$TAG.log 2>&1
 echo "pytest exit $?"
-tail -n 80 gpurun_out/pytest_gpu.log
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err
+tail -n 40 gpurun_out/pytest_gpu_$TAG.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench exit $?"
-tail -c 6000 gpurun_out/bench.log; tail -n 20 gpurun_out/bench.err
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench_$TAG.json").read().strip().splitlines()[-1])
+def line(o):
+    r = o.get("roofline") or {}
+    return "%-24s %8.3f ms/step %10.2f M edges/s   top kernel %-16s %6.1f us frac %.3f" % (
+        o["config"]["workload"], o["ms_per_step"], o["value"] / 1e6, r.get("kernel"), r.get("avg_us", 0), r.get("frac", 0))
+print(line(d))
+for o in d.get("workloads", []):
+    print(line(o))
+print("cpu", d.get("cpu_baseline"))
+for k in d["kernels"]:
+    print("   %-22s x%.0f %7.1f us (pipelined %7.1f) %s frac %.3f" % (k["kernel"], k["launches_per_step"], k["avg_us"], k["avg_us_in_pipeline"], k["bound"], k["frac"]))
+PY
+tail -n 20 gpurun_out/bench_$TAG.err
