@@ -3,7 +3,7 @@
 mkdir -p gpurun_out; : > gpurun_out/ab.log
 for cfg in "$@"; do
   echo "== $cfg" | tee -a gpurun_out/ab.log
-  env $cfg python bench.py --steps 30 --warmup 5 --cpu-steps 0 2>&1 | python -c "
+  env $cfg python bench.py --steps 30 --warmup 5 --cpu-steps 0 --no-extra-workloads 2>&1 | python -c "
 import sys, json
 o = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('ms/step %.4f  edges/s %.0f' % (o['ms_per_step'], o['value']))

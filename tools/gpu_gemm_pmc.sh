@@ -11,3 +11,8 @@ tail -3 $OUT/p1.log | cut -c1-200; tail -3 $OUT/p3.log | cut -c1-200
 python tools/pmc_summary.py $OUT/p1/p1_results.db k_gemm
 python tools/pmc_summary.py $OUT/p2/p2_results.db k_gemm
 python tools/pmc_summary.py $OUT/p3/p3_results.db k_gemm
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/p4 -o p4 -- python tools/gemm_pmc.py > $OUT/p4.log 2>&1
+python tools/pmc_summary.py $OUT/p4/p4_results.db k_gemm
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCP_TCC_READ_REQ_LATENCY_sum -d $OUT/p5 -o p5 -- python tools/gemm_pmc.py > $OUT/p5.log 2>&1
+python tools/pmc_summary.py $OUT/p5/p5_results.db k_gemm
+tail -2 $OUT/p4.log $OUT/p5.log | cut -c1-300
