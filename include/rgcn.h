@@ -68,8 +68,13 @@ enum {
   RGCN_BUF_OUTDEG = 4,     /* int32 [V] out-degree inside the fed graph */
   RGCN_BUF_ROWPTR = 5,     /* int32 [V+1] incidence CSR offsets (owned relations only) */
   RGCN_BUF_NORM_EXCHANGE = 6,   /* float [1] squared norm of this rank's relation-sharded gradients (optimizer phases) */
-  RGCN_BUF_DBASIS_EXCHANGE = 7  /* basis kind: [2,B,d,d] partial gradient of the replicated basis tensors of the
+  RGCN_BUF_DBASIS_EXCHANGE = 7, /* basis kind: [2,B,d,d] partial gradient of the replicated basis tensors of the
                                    backward layer in flight, which a multi-GPU run all-reduces */
+  /* the two orderings graph preparation produces (library's own stable sort, csr_sort.hip), for inspection:
+   * incidence i < E = edge i seen from its object, i >= E = edge i-E seen from its subject; message m likewise with
+   * directed relation r (m < E) or R + r */
+  RGCN_BUF_PERM_VERTEX = 8,     /* int32 [2E] incidence ids in incidence-CSR order (by vertex, ties by id) */
+  RGCN_BUF_PERM_RELATION = 9    /* int32 [2E] message ids in message-list order (by directed relation, ties by id) */
 };
 
 /*

@@ -19,7 +19,7 @@ ABI_VERSION = 1
 KIND_BLOCK, KIND_BASIS = 0, 1
 NORM_INTENDED, NORM_TF_AS_EXECUTED, NORM_NONE = 0, 1, 2
 BUF_EXCHANGE, BUF_SELF, BUF_DSELF_EXCHANGE, BUF_INDEG, BUF_OUTDEG, BUF_ROWPTR, BUF_NORM_EXCHANGE, \
-    BUF_DBASIS_EXCHANGE = range(8)
+    BUF_DBASIS_EXCHANGE, BUF_PERM_VERTEX, BUF_PERM_RELATION = range(10)
 
 KINDS = {"block": KIND_BLOCK, "basis": KIND_BASIS}
 NORMS = {"intended": NORM_INTENDED, "tf_as_executed": NORM_TF_AS_EXECUTED, "none": NORM_NONE}
@@ -317,9 +317,11 @@ class Engine:
             t = t.astype(np.int32)
         t = np.ascontiguousarray(t)
         self._check(self.lib.rgcn_set_graph(self.ctx, _ptr(t), t.shape[0]))
+        self.num_edges = int(t.shape[0])
 
     def set_graph_device(self, dev_buffer, num_edges):
         self._check(self.lib.rgcn_set_graph_device(self.ctx, dev_buffer.ptr, int(num_edges)))
+        self.num_edges = int(num_edges)
 
     def set_relation_owner(self, owner):
         o = np.ascontiguousarray(owner, dtype=np.int32)
@@ -478,6 +480,8 @@ class Engine:
             out = np.empty(self.V, dtype=np.int32)
         elif which == BUF_ROWPTR:
             out = np.empty(self.V + 1, dtype=np.int32)
+        elif which in (BUF_PERM_VERTEX, BUF_PERM_RELATION):
+            out = np.empty(2 * self.num_edges, dtype=np.int32)
         elif which == BUF_DSELF_EXCHANGE:
             out = np.empty((self.d, self.d), dtype=np.float32)
         elif which == BUF_NORM_EXCHANGE:

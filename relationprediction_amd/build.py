@@ -21,7 +21,7 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librgcn.so")
 ARCH = "gfx950"
-SOURCES = ["rgcn_api.hip", "graph_prep.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "basis.hip",
+SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h")]
 # No packed-FP32 VALU instructions anywhere in the library: on gfx950 a v_pk_fma_f32 (and kin) issued

@@ -17,15 +17,6 @@
 // forward pass runs (rgcn_train_step_device).
 #include "rgcn_internal.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-
-// rocprim's default picks a block sort + ~20 merge launches below 1M items: at N = 330,000 that is 45 launches of
-// 5-7 us for the two sorts, launch-bound (0.30 ms).  With 8- to 14-bit keys the onesweep radix path is 12 launches
-// (0.19 ms).  Merge only below 4096 items.  (The encoder's 30,000-item sorts stay on the default: there onesweep's
-// 25 us passes lose to six short merge launches, and its spinning look-back blocks disturb the forward pass.)
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 4096>;
-
 namespace rgcn {
 
 namespace {
@@ -61,8 +52,8 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_
 }
 
 // ---- CSR construction -----------------------------------------------------------------------
-__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t* keyv, int32_t* valv,
-                           uint32_t* keyr, int32_t* valr, int32_t* errflag) {
+__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t* keyv,
+                           uint32_t* keyr, int32_t* errflag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * N) return;
   const bool subj = i < N;
@@ -71,11 +62,7 @@ __global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, u
   const bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
   if (subj && !ok) atomicOr(errflag, 2);
   keyv[i] = ok ? (uint32_t)(subj ? s : o) : (uint32_t)V;
-  valv[i] = i;
-  if (subj) {
-    keyr[n] = ok ? (uint32_t)r : (uint32_t)R;
-    valr[n] = n;
-  }
+  if (subj) keyr[n] = ok ? (uint32_t)r : (uint32_t)R;
 }
 
 // block 0: relation offsets + exclusive scan of the chunk counts; blocks 1..: entity row offsets + long rows
@@ -618,15 +605,8 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)(q.energy_blocks > q.max_chunks ? q.energy_blocks : q.max_chunks)));
   RGCN_TRY(dalloc(c, &q.loss, 1));
   RGCN_TRY(dalloc(c, &q.slab, (size_t)q.max_chunks * d));
-  size_t t1 = 0, t2 = 0;
-  if (N > 0) {
-    RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, q.keyv, q.keyv_s, q.valv, q.permv, 2 * N, 0,
-                                          bits_for((uint32_t)c->V), c->stream));
-    RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(nullptr, t2, q.keyr, q.keyr_s, q.valr, q.permr, N, 0,
-                                          bits_for((uint32_t)c->R), c->stream));
-  }
-  q.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
-  RGCN_HIP(c, hipMalloc(&q.sort_tmp, q.sort_tmp_bytes));
+  RGCN_TRY(dalloc(c, &q.keyv_t, 2 * N)); RGCN_TRY(dalloc(c, &q.keyr_t, N));
+  RGCN_TRY(dalloc(c, &q.tablev, sort_table_elems(2 * N))); RGCN_TRY(dalloc(c, &q.tabler, sort_table_elems(N)));
   RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_ready, hipEventDisableTiming));
   if (!c->dcodes_own) RGCN_HIP(c, hipMalloc((void**)&c->dcodes_own, sizeof(float) * V * d));
   q.maxN = maxN;
@@ -637,7 +617,8 @@ void decoder_free(rgcn_ctx* c) {
   DecoderBufs& q = c->dec;
   void* ptrs[] = {q.keyv, q.keyv_s, q.valv, q.permv, q.keyr, q.keyr_s, q.valr, q.permr, q.row_ptr, q.rel_ptr,
                   q.chunk_ptr, q.e_other, q.e_rel, q.e_trip, q.long_rows, q.nlong, q.dx, q.loss_part, q.loss,
-                  q.slab, q.sort_tmp, q.long_first, q.long_cnt, q.piece_row, q.piece_k, q.piece_slab};
+                  q.slab, q.keyv_t, q.keyr_t, q.tablev, q.tabler, q.long_first, q.long_cnt, q.piece_row, q.piece_k,
+                  q.piece_slab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (q.ev_ready) (void)hipEventDestroy(q.ev_ready);
@@ -657,20 +638,13 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
     {
       ProfScope ps(c, "dec_keys", 36.0 * N, 0);
       hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, q.keyv,
-                         q.valv, q.keyr, q.valr, c->g.errflag);
+                         q.keyr, c->g.errflag);
     }
-    {
-      ProfScope ps(c, "dec_sort_entity", 32.0 * N, 0);
-      size_t tb = q.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(q.sort_tmp, tb, q.keyv, q.keyv_s, q.valv, q.permv, (size_t)2 * N, 0,
-                                            bits_for((uint32_t)V), c->stream));
-    }
-    {
-      ProfScope ps(c, "dec_sort_relation", 16.0 * N, 0);
-      size_t tb = q.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs<SortConfig>(q.sort_tmp, tb, q.keyr, q.keyr_s, q.valr, q.permr, (size_t)N, 0,
-                                            bits_for((uint32_t)R), c->stream));
-    }
+    // entity incidences (2N, by entity) and triples (N, by relation): one call, shared launches
+    SortSpec sp[2];
+    sp[0] = SortSpec{q.keyv, q.keyv_s, q.permv, q.keyv_t, q.valv, nullptr, q.tablev, (int64_t)2 * N, (uint32_t)V};
+    sp[1] = SortSpec{q.keyr, q.keyr_s, q.permr, q.keyr_t, q.valr, nullptr, q.tabler, (int64_t)N, (uint32_t)R};
+    RGCN_TRY(sort_pairs(c, "dec_sort", 2, sp));
   }
   {
     ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);

@@ -16,10 +16,9 @@
 //     (rows = sources): one sort serves both directions.
 //
 // All of it is stream-ordered with no host synchronisation, so a step can be graph-captured.
-// Sorting uses rocPRIM's stable LSD radix sort (deterministic order => deterministic fp32 sums).
+// The two sorts are ONE call of the library's own stable LSD radix sort (csr_sort.hip: both sorts share its
+// launches; deterministic order => deterministic fp32 sums), whose last pass also writes the slot of every incidence.
 #include "rgcn_internal.h"
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace rgcn {
 
@@ -88,8 +87,8 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
 // One thread per incidence: sort keys for the two sorts; the first E threads also count the GLOBAL
 // degrees (all fed edges, owned or not) and validate the ids.
 __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
-                       const int32_t* __restrict__ owner, int rank, uint32_t* keyv, int32_t* valv,
-                       uint32_t* keyr, int32_t* valr, int count_degrees, int32_t* indeg, int32_t* outdeg,
+                       const int32_t* __restrict__ owner, int rank, uint32_t* keyv,
+                       uint32_t* keyr, int count_degrees, int32_t* indeg, int32_t* outdeg,
                        int32_t* errflag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * E) return;
@@ -109,9 +108,7 @@ __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
   }
   bool owned = ok && owner[r] == rank;
   keyv[i] = owned ? (uint32_t)(fwd ? o : s) : (uint32_t)V;   // incidence i sits at this vertex
-  valv[i] = i;
   keyr[i] = owned ? (uint32_t)(fwd ? r : R + r) : (uint32_t)(2 * R);
-  valr[i] = i;
 }
 
 __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_t x) {
@@ -203,11 +200,6 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
     const int i = atomicAdd(nlong, 1);
     if (i < cap) long_rows[i] = v;
   }
-}
-
-__global__ void k_pos(const int32_t* __restrict__ permv, int n, int32_t* pos) {
-  int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot < n) pos[permv[slot]] = slot;
 }
 
 __device__ __forceinline__ int upper_bound_dev(const int32_t* a, int n, int x) {
@@ -337,17 +329,10 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   RGCN_HIP(c, hipMemsetAsync(g.row_ptr, 0, sizeof(int32_t) * (V + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.rel_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.chunk_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
-  // temp storage for the larger of the two sorts (same element count, different bit ranges)
-  size_t t1 = 0, t2 = 0;
-  if (M > 0) {
-    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, g.keyv, g.keyv_s, g.valv, g.permv, M, 0,
-                                          bits_for((uint32_t)c->V), c->stream));
-    RGCN_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, g.keyr, g.keyr_s, g.valr, g.permr, M, 0,
-                                          bits_for((uint32_t)(2 * c->R)), c->stream));
-  }
-  g.sort_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
-  RGCN_HIP(c, hipMalloc(&g.sort_tmp, g.sort_tmp_bytes));
-  RGCN_HIP(c, hipMalloc(&g.sort_tmp2, g.sort_tmp_bytes));
+  RGCN_TRY(dalloc(c, &g.keyv_t, M));
+  RGCN_TRY(dalloc(c, &g.keyr_t, M));
+  RGCN_TRY(dalloc(c, &g.tablev, sort_table_elems(M)));
+  RGCN_TRY(dalloc(c, &g.tabler, sort_table_elems(M)));
   return RGCN_OK;
 }
 
@@ -358,8 +343,7 @@ static void graph_free_one(GraphBufs& g, bool owns_shared) {
   void* ptrs[] = {g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row, g.piece_k, g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel,
-                  g.s_norm, g.owner, g.errflag, g.sort_tmp,
-                  g.sort_tmp2};
+                  g.s_norm, g.owner, g.errflag, g.keyv_t, g.keyr_t, g.tablev, g.tabler};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g = GraphBufs();
@@ -392,27 +376,13 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
-                         c->rank, g.keyv, g.valv, g.keyr, g.valr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg,
-                         g.errflag);
+                         c->rank, g.keyv, g.keyr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg, g.errflag);
     }
-    {   // the two sorts are independent: relation sort on a side stream
-      StreamScope side(c, 0);
-      ProfScope ps(c, "prep_sort_relation", 16.0 * M, 0);
-      size_t tb = g.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp2, tb, g.keyr, g.keyr_s, g.valr, g.permr,
-                                            (size_t)M, 0, bits_for((uint32_t)(2 * R)), c->stream));
-    }
-    {
-      ProfScope ps(c, "prep_sort_vertex", 16.0 * M, 0);
-      size_t tb = g.sort_tmp_bytes;
-      RGCN_HIP(c, rocprim::radix_sort_pairs(g.sort_tmp, tb, g.keyv, g.keyv_s, g.valv, g.permv,
-                                            (size_t)M, 0, bits_for((uint32_t)V), c->stream));
-    }
-    {
-      ProfScope ps(c, "prep_pos", 8.0 * M, 0);
-      hipLaunchKernelGGL(k_pos, dim3((M + T - 1) / T), dim3(T), 0, c->stream, g.permv, M, g.pos);
-    }
-    RGCN_TRY(stream_join(c, 0));
+    // incidences by vertex (-> permv, pos) and messages by directed relation (-> permr), in the same launches
+    SortSpec sp[2];
+    sp[0] = SortSpec{g.keyv, g.keyv_s, g.permv, g.keyv_t, g.valv, g.pos, g.tablev, (int64_t)M, (uint32_t)V};
+    sp[1] = SortSpec{g.keyr, g.keyr_s, g.permr, g.keyr_t, g.valr, nullptr, g.tabler, (int64_t)M, (uint32_t)(2 * R)};
+    RGCN_TRY(sort_pairs(c, "prep_sort", 2, sp));
   }
   {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);

@@ -148,9 +148,8 @@ struct GraphBufs {
   int32_t *d_src = nullptr, *d_rel = nullptr, *s_dst = nullptr, *s_rel = nullptr;
   float *d_norm = nullptr, *s_norm = nullptr;
   float* m_norm = nullptr;
-  void* sort_tmp = nullptr;
-  void* sort_tmp2 = nullptr;    // second radix-sort workspace (relation sort on a side stream)
-  size_t sort_tmp_bytes = 0;
+  uint32_t *keyv_t = nullptr, *keyr_t = nullptr;   // sort scratch (csr_sort.hip)
+  uint16_t *tablev = nullptr, *tabler = nullptr;
   // prefetch bookkeeping (rgcn_prefetch_graph_device): which graph this set was prepared for
   const int32_t* pf_tri = nullptr;
   int64_t pf_E = -1;
@@ -179,8 +178,8 @@ struct DecoderBufs {
   int32_t long_cap = 0, piece_cap = 0, max_chunks = 0, energy_blocks = 0;
   float *dx = nullptr, *loss_part = nullptr, *slab = nullptr;
   double* loss = nullptr;
-  void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
+  uint32_t *keyv_t = nullptr, *keyr_t = nullptr;   // sort scratch (csr_sort.hip)
+  uint16_t *tablev = nullptr, *tabler = nullptr;
   hipEvent_t ev_ready = nullptr;
   bool loss_valid = false;
 };
@@ -310,6 +309,21 @@ struct ProfScope {
 rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share);
 void graph_free(rgcn_ctx* c);
 rgcn_status graph_build(rgcn_ctx* c, const int32_t* triples_dev, int64_t E);
+
+// ---- csr_sort.hip: stable sort of (key, position) pairs by a small integer key, up to two sorts per call
+struct SortSpec {
+  const uint32_t* key_in;   // n keys, each <= max_key < 2^24
+  uint32_t* key_out;        // sorted keys
+  int32_t* val_out;         // original positions in key order (ties in position order)
+  uint32_t* key_tmp;        // scratch, n elements each
+  int32_t* val_tmp;
+  int32_t* pos_out;         // optional: pos_out[position] = slot (inverse of val_out)
+  uint16_t* table;          // scratch, sort_table_elems(n) elements
+  int64_t n;
+  uint32_t max_key;
+};
+size_t sort_table_elems(size_t n);
+rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* specs);
 
 // ---- gemm_f32.hip
 // C[M,N] (ldc) = A(m,k) . B(k,n).  a_kc: A stored [m][k] (k contiguous, lda) else [k][m];

@@ -154,6 +154,34 @@ def test_graph_prep_degrees_and_csr(native):
     np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(cnt)]))
 
 
+@pytest.mark.parametrize("V,R,E", [(97, 5, 400), (14541, 237, 15000), (40943, 18, 10000), (300, 1345, 2049),
+                                   (70000, 3, 5000), (14541, 237, 38001)])
+def test_graph_prep_orderings_equal_a_stable_sort(native, V, R, E):
+    """the library's own sort (csr_sort.hip) against numpy's stable argsort: incidences by vertex and messages by
+    directed relation, ties in index order -- bit-exact (integer work), incl. more than one 2048-item block, a key
+    range above 16 bits (three radix passes) and hub rows"""
+    rng = np.random.RandomState(V + E)
+    hub = rng.randint(0, V, 8)
+    s = np.where(rng.rand(E) < 0.2, hub[rng.randint(0, 8, E)], rng.randint(0, V, E))
+    o = np.where(rng.rand(E) < 0.2, hub[rng.randint(0, 8, E)], rng.randint(0, V, E))
+    r = np.minimum((rng.pareto(1.0, E) * 3).astype(np.int64), R - 1)
+    triples = np.stack([s, r, o], 1).astype(np.int32)
+    eng = native.Engine(V, R, 8, 1, "block", 2, max_edges=E)
+    try:
+        eng.set_graph(triples)
+        eng.sync()
+        permv = eng.read_buffer(native.BUF_PERM_VERTEX)
+        permr = eng.read_buffer(native.BUF_PERM_RELATION)
+        rowptr = eng.read_buffer(native.BUF_ROWPTR)
+    finally:
+        eng.close()
+    keyv = np.concatenate([triples[:, 2], triples[:, 0]])
+    keyr = np.concatenate([triples[:, 1], R + triples[:, 1]])
+    np.testing.assert_array_equal(permv, np.argsort(keyv, kind="stable"))
+    np.testing.assert_array_equal(permr, np.argsort(keyr, kind="stable"))
+    np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(keyv, minlength=V))]))
+
+
 # ------------------------------------------------------------------ encoder forward + backward
 BLOCK_CASES = [
     # V, R, d, L, nb, E
