@@ -149,6 +149,20 @@ rgcn_status rgcn_get_grad(rgcn_ctx* ctx, int32_t index, float* host, int64_t cou
 rgcn_status rgcn_set_graph(rgcn_ctx* ctx, const int32_t* triples_host, int64_t num_edges);
 rgcn_status rgcn_set_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev, int64_t num_edges);
 
+/* Edge dropout of the reference's minibatch construction, on the device (code/train.py:233-238):
+ *     graph_split_ids = np.random.choice(graph_batch_ids, size=int(GraphSplitSize * n), replace=False)
+ * the message-passing graph is a uniformly random subset of EXACTLY `keep` of the n batch edges; only those are fed
+ * to `graph_edges`, so degrees and normalisation are counted over the kept edges, while the decoder keeps
+ * every batch edge as a positive (H9: pass the whole batch to the decoder / rgcn_train_step_minibatch_device).
+ * batch_dev = int32 [n,3]; the draw is a function of (seed, n, keep) alone (counter-based keys, the `keep` smallest
+ * win); keep_mask_dev (nullable) = uint8 [n] with exactly `keep` ones: the caller's set instead of the draw (how a
+ * test injects the reference's choice).  The kept edges are compacted in batch order (the reference's come in the
+ * random order of np.random.choice: same set distribution, other row order) and prepared like rgcn_set_graph_device;
+ * rgcn_get_graph_edges returns the rows of the graph currently set ([keep,3]; synchronises). */
+rgcn_status rgcn_set_graph_dropout_device(rgcn_ctx* ctx, const int32_t* batch_dev, int64_t num_edges, int64_t keep,
+                                          uint64_t seed, const uint8_t* keep_mask_dev);
+rgcn_status rgcn_get_graph_edges(rgcn_ctx* ctx, int32_t* host, int64_t count);
+
 /* ---- forward: get_all_codes(mode) (message_gcn.py:44-79, affine_transform.py:63-83) ------------
  * train != 0 applies self-loop dropout (message_gcn.py:60-64).  The Bernoulli(keep_prob) draw is
  *   - dropout_masks_host != NULL: the caller's uint8 [L,V,d] 0/1 masks (parity testing), else
@@ -248,6 +262,16 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, in
                                    const int32_t* x_dev, const float* y_dev, int64_t num_triples,
                                    uint64_t dropout_seed, float regularization_parameter);
 
+/* The reference's t_func after the neighbourhood sampling + update_from_batch (code/train.py:227-245,
+ * optimize.py:81-88) in ONE asynchronous call on a graph batch that is resident in HBM: edge dropout (exact `keep`
+ * of the n batch edges -> message graph, as rgcn_set_graph_dropout_device with edge_seed), negative sampling
+ * (rgcn_negative_sample_device on ALL n batch edges -> x_scratch_dev int32 [n*(rate+1),3], y_scratch_dev float
+ * [n*(rate+1)]), then the train step of rgcn_train_step_device.  Only the n batch triples cross PCIe per step. */
+rgcn_status rgcn_train_step_minibatch_device(rgcn_ctx* ctx, const int32_t* batch_dev, int64_t num_edges, int64_t keep,
+                                             uint64_t edge_seed, int32_t negative_rate, uint64_t negative_seed,
+                                             int32_t* x_scratch_dev, float* y_scratch_dev, uint64_t dropout_seed,
+                                             float regularization_parameter);
+
 /* Software pipelining across steps: prepare the graph structures of the NEXT minibatch (same work as
  * rgcn_set_graph_device) on a side stream into a second buffer set while the step already queued
  * keeps running.  A later rgcn_step_device with the same (pointer, num_edges) adopts them instead of
@@ -258,6 +282,10 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* ctx, const int32_t* triples_dev, in
  * step then rebuilds in line); writes the library cannot see (the caller's own kernels / copies) are the
  * caller's responsibility -- call rgcn_prefetch_graph_device again after them. */
 rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* ctx, const int32_t* triples_dev_next, int64_t num_edges);
+/* the same for a step that draws its graph by edge dropout: adopted by rgcn_train_step_minibatch_device called with
+ * the same (batch pointer, num_edges, keep, edge seed) */
+rgcn_status rgcn_prefetch_graph_dropout_device(rgcn_ctx* ctx, const int32_t* batch_dev_next, int64_t num_edges,
+                                               int64_t keep, uint64_t edge_seed);
 
 /* ---- hipGraph capture of whole steps (BASELINE config 5: "hipGraph-captured train step") -------------
  * Between rgcn_capture_begin and rgcn_capture_end every asynchronous device call on the context

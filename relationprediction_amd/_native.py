@@ -85,6 +85,11 @@ _SIGS = {
     "rgcn_optimizer_apply": (C.c_int32, [_P]),
     "rgcn_train_step_device": (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint64, C.c_float]),
     "rgcn_prefetch_graph_device": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_prefetch_graph_dropout_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.c_uint64]),
+    "rgcn_set_graph_dropout_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, _P]),
+    "rgcn_get_graph_edges": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_train_step_minibatch_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_int32, C.c_uint64,
+                                                     _P, _P, C.c_uint64, C.c_float]),
     "rgcn_set_relation_owner": (C.c_int32, [_P, _P, C.c_int32]),
     "rgcn_comm_unique_id": (C.c_int32, [_P]),
     "rgcn_comm_init": (C.c_int32, [_P, _P]),
@@ -322,6 +327,30 @@ class Engine:
     def set_graph_device(self, dev_buffer, num_edges):
         self._check(self.lib.rgcn_set_graph_device(self.ctx, dev_buffer.ptr, int(num_edges)))
         self.num_edges = int(num_edges)
+
+    def set_graph_dropout_device(self, batch_buffer, num_edges, keep, seed=0, keep_mask=None):
+        """graph = exact-`keep` random subset of the batch's edges, drawn on the device (rgcn_set_graph_dropout_device);
+        keep_mask: a DeviceBuffer with uint8 [num_edges] holding the caller's choice instead"""
+        self._check(self.lib.rgcn_set_graph_dropout_device(self.ctx, batch_buffer.ptr, int(num_edges), int(keep),
+                                                           C.c_uint64(seed), keep_mask.ptr if keep_mask else None))
+        self.num_edges = int(keep)
+
+    def graph_edges(self):
+        """the [E,3] rows of the graph currently set (after edge dropout, if any)"""
+        out = np.empty((self.num_edges, 3), dtype=np.int32)
+        self._check(self.lib.rgcn_get_graph_edges(self.ctx, _ptr(out), self.num_edges))
+        return out
+
+    def prefetch_graph_dropout_device(self, batch_buffer, num_edges, keep, seed):
+        self._check(self.lib.rgcn_prefetch_graph_dropout_device(self.ctx, batch_buffer.ptr, int(num_edges), int(keep),
+                                                                C.c_uint64(seed)))
+
+    def train_step_minibatch_device(self, batch_buffer, num_edges, keep, edge_seed, rate, negative_seed, x_dev, y_dev,
+                                    seed=0, reg_param=0.01):
+        self._check(self.lib.rgcn_train_step_minibatch_device(
+            self.ctx, batch_buffer.ptr, int(num_edges), int(keep), C.c_uint64(edge_seed), int(rate),
+            C.c_uint64(negative_seed), x_dev.ptr, y_dev.ptr, C.c_uint64(seed), C.c_float(reg_param)))
+        self.num_edges = int(keep)
 
     def set_relation_owner(self, owner):
         o = np.ascontiguousarray(owner, dtype=np.int32)

@@ -253,6 +253,95 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
   }
 }
 
+// ---- edge dropout on the device (reference: code/train.py:233-238) ----------------------------------------------
+// The reference draws the message-passing graph of a step as np.random.choice(batch, size=k, replace=False): a
+// uniformly random k-subset of the graph batch (exact k, no replacement), and only THOSE edges are fed to
+// `graph_edges`, so degrees / normalisation see the kept edges alone while the decoder keeps every batch
+// edge as a positive (H9).  Here: every batch edge e gets the 64-bit key (40 random bits of a counter-based generator
+// keyed by (seed, e)) << 24 | e -- all keys distinct -- and the k smallest keys are kept, which is a uniform k-subset.
+// The k-th smallest key is found by an 8-pass radix select (one LDS histogram per byte, keys recomputed on the fly,
+// nothing stored), then the kept edges are compacted in batch order.  One workgroup, one launch, deterministic.
+// keep_mask != nullptr: the caller's 0/1 choice instead of the draw (parity tests inject the reference's set).
+__device__ __forceinline__ uint64_t dropout_edge_key(uint64_t seed, uint32_t e) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)e + 0x51ED27ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= (z >> 31);
+  return (z & 0xFFFFFFFFFF000000ull) | (uint64_t)e;
+}
+
+__global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict__ batch, int n, int keep, uint64_t seed,
+                                                       const uint8_t* __restrict__ keep_mask,
+                                                       int32_t* __restrict__ out, int32_t* errflag) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint64_t prefix_s;
+  __shared__ uint32_t want_s;
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint64_t thresh = 0;      // keep iff key <= thresh (only used without a mask)
+  if (keep_mask == nullptr && keep > 0 && keep < n) {
+    if (tid == 0) { prefix_s = 0; want_s = (uint32_t)keep; }
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 8 * (7 - pass);
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint64_t prefix = prefix_s;
+      for (int e = tid; e < n; e += 1024) {
+        const uint64_t key = dropout_edge_key(seed, (uint32_t)e);
+        const bool in = pass == 0 || (key >> (shift + 8)) == prefix;
+        if (in) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {           // 256 bins: the bin in which the running count reaches what is still wanted
+        uint32_t want = want_s, run = 0;
+        int b = 0;
+        for (; b < 255; ++b) {
+          if (run + hist[b] >= want) break;
+          run += hist[b];
+        }
+        prefix_s = (prefix << 8) | (uint64_t)b;
+        want_s = want - run;
+      }
+      __syncthreads();
+    }
+    thresh = prefix_s;
+  }
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  // stable compaction, 1024 edges per round
+  for (int e0 = 0; e0 < n; e0 += 1024) {
+    const int e = e0 + tid;
+    bool kept = false;
+    if (e < n) {
+      if (keep_mask != nullptr) kept = keep_mask[e] != 0;
+      else kept = keep >= n || (keep > 0 && dropout_edge_key(seed, (uint32_t)e) <= thresh);
+    }
+    const unsigned long long vote = __ballot(kept);
+    const int rank = __popcll(vote & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wid] = __popcll(vote);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) before += wsum[w];
+      total += wsum[w];
+    }
+    const int base = base_s;
+    if (kept) {
+      const int slot = base + before + rank;
+      if (slot < keep) {
+        out[3 * slot] = batch[3 * e];
+        out[3 * slot + 1] = batch[3 * e + 1];
+        out[3 * slot + 2] = batch[3 * e + 2];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) base_s = base + total;
+    __syncthreads();
+  }
+  if (tid == 0 && base_s != keep) atomicOr(errflag, 4);     // a mask that does not hold exactly `keep` ones
+}
+
 int bits_for(uint32_t max_value) {
   int b = 1;
   while (b < 32 && (1ull << b) <= max_value) ++b;
@@ -409,6 +498,19 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   RGCN_HIP(c, hipGetLastError());
   g.ready = true;
   return RGCN_OK;
+}
+
+// graph = the kept edges of `batch` under edge dropout (k_edge_dropout), compacted into the set's own triple buffer
+rgcn_status graph_build_dropout(rgcn_ctx* c, const int32_t* batch, int64_t n, int64_t keep, uint64_t seed,
+                                const uint8_t* keep_mask) {
+  GraphBufs& g = c->g;
+  if (n > 0) {
+    ProfScope ps(c, "prep_edge_dropout", 12.0 * n + 12.0 * keep, 0);
+    hipLaunchKernelGGL(k_edge_dropout, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed, keep_mask,
+                       g.triples, g.errflag);
+    RGCN_HIP(c, hipGetLastError());
+  }
+  return graph_build(c, g.triples, keep);
 }
 
 }  // namespace rgcn

@@ -145,8 +145,9 @@ static rgcn_status check_dev_flag(rgcn_ctx* c, bool main_only = false) {
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   if (flag) {
     RGCN_HIP(c, hipMemsetAsync(c->g.errflag, 0, sizeof(int32_t), c->stream));
-    RGCN_FAIL(c, RGCN_ERR_INVALID, "graph_edges contains a vertex id outside [0,EntityCount) or a "
-                                   "relation id outside [0,RelationCount)");
+    RGCN_FAIL(c, RGCN_ERR_INVALID, std::string(flag & 4 ? "edge dropout: the keep mask does not hold exactly `keep` ones; " : "") +
+                                   (flag & 3 ? "graph_edges / the decoder batch contains a vertex id outside [0,EntityCount) or a "
+                                               "relation id outside [0,RelationCount)" : ""));
   }
   return RGCN_OK;
 }
@@ -783,10 +784,12 @@ rgcn_status rgcn_backward(rgcn_ctx* c, const float* dcodes_host, int64_t count) 
 // Start of a step: mark the point a prefetch may fork from, then adopt the prefetched structures of this
 // graph or build them in line.  While a hipGraph is being captured, events recorded BEFORE the capture began
 // must not be waited on (the replayed graph is ordered behind everything earlier on the stream anyway).
-static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
+// keep >= 0: the graph is the edge-dropout subset (keep of the E batch edges, generator key eseed) of tri_dev.
+static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int64_t keep = -1, uint64_t eseed = 0) {
   RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
   c->step_begin_in_capture = c->capturing;
-  if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E) {
+  if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E && c->g_alt.pf_keep == keep &&
+      (keep < 0 || c->g_alt.pf_eseed == eseed)) {
     // the structures for this graph were prepared beside the previous step: swap them in
     std::swap(c->g, c->g_alt);
     c->g.pf_valid = false;
@@ -794,7 +797,7 @@ static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
     if (!c->capturing || c->g.ready_in_capture) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->g.ev_ready, 0));
     return RGCN_OK;
   }
-  return graph_build(c, tri_dev, E);
+  return keep < 0 ? graph_build(c, tri_dev, E) : graph_build_dropout(c, tri_dev, E, keep, eseed, nullptr);
 }
 static rgcn_status step_end(rgcn_ctx* c) {
   RGCN_HIP(c, hipEventRecord(c->g.ev_free, c->main_stream));
@@ -894,15 +897,10 @@ rgcn_status rgcn_optimizer_step(rgcn_ctx* c) {
 rgcn_status rgcn_optimizer_norm_partial(rgcn_ctx* c) { RGCN_NEED(c); return optimizer_norm_partial(c); }
 rgcn_status rgcn_optimizer_apply(rgcn_ctx* c) { RGCN_NEED(c); return optimizer_apply(c); }
 
-rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, const int32_t* X_dev,
-                                   const float* Y_dev, int64_t N, uint64_t seed, float reg_param) {
-  RGCN_NEED(c);
-  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
-  if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
-  if (c->world > 1 && !c->comm)
-    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
-  if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
-  RGCN_TRY(step_begin(c, tri_dev, E));
+// everything of a train step behind the graph preparation: encoder forward, decoder loss + gradients, encoder
+// backward, clip + Adam
+static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const float* Y_dev, int64_t N, uint64_t seed,
+                                   float reg_param) {
   RGCN_TRY(forward_all(c, 1, seed, nullptr));
   // The decoder batch's CSRs depend on X only.  They are built on side stream 1, forked at the START of the step,
   // but enqueued AFTER the encoder's prep and forward: their two sorts are ~45 launches of a few microseconds, and
@@ -926,9 +924,9 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t 
   return RGCN_OK;
 }
 
-rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
-  RGCN_NEED(c);
+static rgcn_status prefetch_impl(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int64_t keep, uint64_t eseed) {
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (keep > E) RGCN_FAIL(c, RGCN_ERR_INVALID, "edge dropout: keep outside [0, num_edges]");
   if (E > 0 && !tri_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
   // build into the INACTIVE set on the prefetch stream; it only has to wait for the last step that
   // used that set (not for the step currently queued on the main stream)
@@ -945,7 +943,7 @@ rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int6
     } else if (hipStreamWaitEvent(c->pf_stream, c->g.ev_free, 0) != hipSuccess) { s = RGCN_ERR_HIP; c->err = "hipStreamWaitEvent"; break; }
     c->stream = c->pf_stream;
     const bool was_done = c->fwd_done;
-    s = graph_build(c, tri_dev, E);
+    s = keep < 0 ? graph_build(c, tri_dev, E) : graph_build_dropout(c, tri_dev, E, keep, eseed, nullptr);
     c->fwd_done = was_done;          // the ACTIVE set's forward state is untouched
     c->stream = c->main_stream;
     if (s != RGCN_OK) break;
@@ -953,11 +951,78 @@ rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int6
     c->g.ready_in_capture = c->capturing;
     c->g.pf_tri = tri_dev;
     c->g.pf_E = E;
+    c->g.pf_keep = keep;
+    c->g.pf_eseed = eseed;
     c->g.pf_valid = true;
   } while (0);
   c->stream = c->main_stream;
   std::swap(c->g, c->g_alt);
   return s;
+}
+
+rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, const int32_t* X_dev,
+                                   const float* Y_dev, int64_t N, uint64_t seed, float reg_param) {
+  RGCN_NEED(c);
+  if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (!X_dev || !Y_dev || N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad decoder batch");
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
+  if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
+  RGCN_TRY(step_begin(c, tri_dev, E));
+  return train_step_tail(c, X_dev, Y_dev, N, seed, reg_param);
+}
+
+rgcn_status rgcn_prefetch_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E) {
+  RGCN_NEED(c);
+  return prefetch_impl(c, tri_dev, E, -1, 0);
+}
+rgcn_status rgcn_prefetch_graph_dropout_device(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int64_t keep,
+                                               uint64_t seed) {
+  RGCN_NEED(c);
+  if (keep < 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "edge dropout: keep outside [0, num_edges]");
+  return prefetch_impl(c, batch_dev, n, keep, seed);
+}
+
+rgcn_status rgcn_set_graph_dropout_device(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int64_t keep, uint64_t seed,
+                                          const uint8_t* keep_mask_dev) {
+  RGCN_NEED(c);
+  if (n < 0 || n > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
+  if (keep < 0 || keep > n) RGCN_FAIL(c, RGCN_ERR_INVALID, "edge dropout: keep outside [0, num_edges]");
+  if (n >= ((int64_t)1 << 24)) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "edge dropout: more than 2^24 batch edges");
+  if (n > 0 && !batch_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
+  return graph_build_dropout(c, batch_dev, n, keep, seed, keep_mask_dev);
+}
+
+rgcn_status rgcn_get_graph_edges(rgcn_ctx* c, int32_t* host, int64_t count) {
+  RGCN_NEED(c);
+  if (!c->g.ready) RGCN_FAIL(c, RGCN_ERR_STATE, "no graph has been set");
+  if (count != c->g.E || (count > 0 && !host)) RGCN_FAIL(c, RGCN_ERR_INVALID, "need an [E,3] host buffer of the current graph's size");
+  if (count == 0) return RGCN_OK;
+  RGCN_TRY(check_dev_flag(c));
+  return to_host(c, host, c->g.cur, sizeof(int32_t) * 3 * (size_t)count);
+}
+
+rgcn_status rgcn_train_step_minibatch_device(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int64_t keep,
+                                             uint64_t edge_seed, int32_t negative_rate, uint64_t negative_seed,
+                                             int32_t* x_scratch_dev, float* y_scratch_dev, uint64_t dropout_seed,
+                                             float reg_param) {
+  RGCN_NEED(c);
+  if (n <= 0 || n > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [1, max_edges]");
+  if (keep < 0 || keep > n) RGCN_FAIL(c, RGCN_ERR_INVALID, "edge dropout: keep outside [0, num_edges]");
+  if (n >= ((int64_t)1 << 24)) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "edge dropout: more than 2^24 batch edges");
+  if (negative_rate < 0 || negative_rate > 1024 || !batch_dev || !x_scratch_dev || !y_scratch_dev)
+    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  const int64_t N = n * (int64_t)(negative_rate + 1);
+  if (c->world > 1 && !c->comm)
+    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
+  if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
+  // the message graph: adopted from the prefetch of this very (batch, keep, seed), or drawn and prepared in line
+  RGCN_TRY(step_begin(c, batch_dev, n, keep, edge_seed));
+  // the decoder batch: all n batch edges as positives (the dropped ones included) + their corruptions
+  RGCN_TRY(negative_sample(c, batch_dev, n, negative_rate, negative_seed, x_scratch_dev, y_scratch_dev));
+  // the decoder's batch preparation forks from ev_step_begin onto a side stream: it must see the sampled batch
+  RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
+  return train_step_tail(c, x_scratch_dev, y_scratch_dev, N, dropout_seed, reg_param);
 }
 
 // ---- hipGraph capture of whole steps --------------------------------------------------------------

@@ -153,6 +153,8 @@ struct GraphBufs {
   // prefetch bookkeeping (rgcn_prefetch_graph_device): which graph this set was prepared for
   const int32_t* pf_tri = nullptr;
   int64_t pf_E = -1;
+  int64_t pf_keep = -1;         // >= 0: prepared under edge dropout (keep of pf_E batch edges, seed pf_eseed)
+  uint64_t pf_eseed = 0;
   bool pf_valid = false;
   hipEvent_t ev_ready = nullptr;   // recorded on the prefetch stream when the set is complete
   hipEvent_t ev_free = nullptr;    // recorded on the main stream when the last step using the set ended
@@ -309,6 +311,8 @@ struct ProfScope {
 rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share);
 void graph_free(rgcn_ctx* c);
 rgcn_status graph_build(rgcn_ctx* c, const int32_t* triples_dev, int64_t E);
+rgcn_status graph_build_dropout(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int64_t keep, uint64_t seed,
+                                const uint8_t* keep_mask_dev);
 
 // ---- csr_sort.hip: stable sort of (key, position) pairs by a small integer key, up to two sorts per call
 struct SortSpec {

@@ -88,6 +88,13 @@ class BilinearDiag(Model):
         """feed the next train step beside the running one (runtime.stage)"""
         self.next_component.get_runtime().stage(graph_edges, batch)
 
+    def device_train_step_minibatch(self, minibatch, seed):
+        """the whole iteration from the graph batch on: edge dropout, negatives, train step, all on the device"""
+        self.next_component.get_runtime().train_step_minibatch(minibatch, self.regularization_parameter, seed)
+
+    def device_stage_minibatch(self, minibatch):
+        self.next_component.get_runtime().stage_minibatch(minibatch)
+
     def device_loss(self):
         return self.next_component.get_runtime().loss()
 

@@ -195,6 +195,12 @@ class Model(object):
     def device_stage(self, *args):
         return self.__delegate__('device_stage', *args)
 
+    def device_train_step_minibatch(self, *args):
+        return self.__delegate__('device_train_step_minibatch', *args)
+
+    def device_stage_minibatch(self, *args):
+        return self.__delegate__('device_stage_minibatch', *args)
+
     def device_loss(self):
         return self.__delegate__('device_loss')
 

@@ -272,6 +272,15 @@ class DeviceNegatives(object):
         self.graph_edges, self.batch, self.rate = graph_edges, batch, int(rate)
 
 
+class DeviceMinibatch(object):
+    """A processed batch that leaves BOTH random draws of the reference's t_func to the device step: which `keep` of
+    the batch's edges the encoder sees (edge dropout, train.py:233-238) and the corruptions (auxilliaries.py:13-33).
+    Only `batch` crosses PCIe (rgcn_train_step_minibatch_device)."""
+
+    def __init__(self, batch, keep, edge_seed, rate):
+        self.batch, self.keep, self.edge_seed, self.rate = batch, int(keep), int(edge_seed), int(rate)
+
+
 class HipOptimizer(object):
     """TensorflowOptimizer's role (optimize.py:42-90) on the device train step."""
 
@@ -288,6 +297,9 @@ class HipOptimizer(object):
 
     def update_from_batch(self, processed_batch, seed):
         """Enqueue one train step; processed_batch = (graph_edges, X, Y) as the transform function returns."""
+        if isinstance(processed_batch, DeviceMinibatch):
+            self.model.device_train_step_minibatch(processed_batch, seed)
+            return
         if isinstance(processed_batch, DeviceNegatives):
             self.model.device_train_step_negatives(processed_batch.graph_edges, processed_batch.batch,
                                                    processed_batch.rate, seed)
@@ -300,7 +312,9 @@ class HipOptimizer(object):
         stage = getattr(self.model, 'device_stage', None)
         if stage is None:
             return
-        if isinstance(processed_batch, DeviceNegatives):
+        if isinstance(processed_batch, DeviceMinibatch):
+            self.model.device_stage_minibatch(processed_batch)
+        elif isinstance(processed_batch, DeviceNegatives):
             stage(processed_batch.graph_edges, processed_batch.batch)
         else:
             stage(processed_batch[0], None)

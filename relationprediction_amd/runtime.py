@@ -127,6 +127,41 @@ class EncoderRuntime(object):
             self.engine.copy_to_device_async(bd, b)
         self._staged = (graph_edges, batch, slot, gd, len(g), bd, nb)
 
+    def stage_minibatch(self, mb):
+        """The device-dropout flavour of stage(): ONE upload (the graph batch; it is the edge-dropout input and the
+        decoder's positives at once) on the prefetch stream, then the draw of the kept edges and the preparation of
+        their graph there, beside the running step (rgcn_prefetch_graph_dropout_device)."""
+        b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
+        if len(b) > self.engine.max_edges:
+            return
+        slot = getattr(self, "_slot", 0) ^ 1
+        bd = self._buffer("mbatch%d" % slot, b.nbytes)
+        self.engine.copy_to_device_async(bd, b, on_prefetch_stream=True)
+        self.engine.prefetch_graph_dropout_device(bd, len(b), mb.keep, mb.edge_seed)
+        self._staged = (mb, None, slot, bd, len(b), None, 0)
+
+    def train_step_minibatch(self, mb, reg_param, seed):
+        """One iteration from a graph batch resident on the device: edge dropout, negative sampling and the train
+        step in one asynchronous call (rgcn_train_step_minibatch_device)."""
+        b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
+        n = len(b) * (int(mb.rate) + 1)
+        if n == 0:
+            raise ValueError("empty decoder batch")
+        if len(b) > self.engine.max_edges:
+            raise ValueError("graph batch of %d edges exceeds the context's max_edges %d"
+                             % (len(b), self.engine.max_edges))
+        if n > self._dec_reserved:
+            self.engine.decoder_reserve(n)
+            self._dec_reserved = n
+        st = self._take_staged(mb, None)
+        bd = st[3] if st is not None else self._upload("mbatch", b)
+        xd, yd = self._buffer("X", 12 * n), self._buffer("Y", 4 * n)
+        self.engine.train_step_minibatch_device(bd, len(b), mb.keep, mb.edge_seed, mb.rate, seed ^ 0x5bd1e995, xd, yd,
+                                                seed=seed, reg_param=reg_param)
+        self._state = None
+        self._graph_version = None
+        self.weights_version += 1
+
     def _take_staged(self, graph_edges, batch):
         st = getattr(self, "_staged", None)
         self._staged = None

@@ -33,7 +33,7 @@ def load_dataset(dataset, metric='MRR'):
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
 
-def make_transform(train_triplets, general_settings, encoder, device_negatives=False):
+def make_transform(train_triplets, general_settings, encoder, device_negatives=False, device_dropout=False):
     """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y).
 
     Every batch is a function of ONE seed drawn from numpy's global generator when the batch is requested, so
@@ -63,8 +63,11 @@ def make_transform(train_triplets, general_settings, encoder, device_negatives=F
         else:
             graph_batch_ids = np.arange(arr.shape[0])
         graph_batch = train_triplets[graph_batch_ids]
-        # edge dropout: the encoder sees a random GraphSplitSize fraction of the batch (exact-k, host side, :235-238)
+        # edge dropout: the encoder sees a random GraphSplitSize fraction of the batch (exact-k, :235-238)
         split_size = int(float(general_settings['GraphSplitSize']) * graph_batch.shape[0])
+        if device_dropout:            # both draws (kept edges, corruptions) are made by the device step
+            from .optimization.optimize import DeviceMinibatch
+            return DeviceMinibatch(graph_batch, split_size, rng.randint(0, 2 ** 31 - 1), ns.negative_sample_rate)
         graph_split_ids = rng.choice(graph_batch_ids, size=split_size, replace=False)
         graph_split = train_triplets[graph_split_ids]
         if device_negatives:          # corruptions are drawn by the device step (optimize.DeviceNegatives)
@@ -88,6 +91,9 @@ def main(argv=None):
                         help="stop after this many iterations (sets Optimizer.MaxIterations)")
     parser.add_argument("--host-negatives", action="store_true",
                         help="draw the negative samples with the reference's numpy code on the host instead of on the device")
+    parser.add_argument("--host-edge-dropout", action="store_true",
+                        help="choose the GraphSplitSize subset of each graph batch with numpy on the host (the "
+                             "reference's np.random.choice) instead of on the device")
     parser.add_argument("--batch-workers", type=int, default=8,
                         help="background threads that build minibatches ahead of the device (0: build in line)")
     args = parser.parse_args(argv)
@@ -143,7 +149,9 @@ def main(argv=None):
 
     if 'NegativeSampleRate' in general_settings:
         opp.set_sample_transform_function(make_transform(train_triplets, general_settings, encoder,
-                                                         device_negatives=not args.host_negatives))
+                                                         device_negatives=not args.host_negatives,
+                                                         device_dropout=not (args.host_negatives or
+                                                                             args.host_edge_dropout)))
 
     model.preprocess(train_triplets)
     model.register_for_test(train_triplets)

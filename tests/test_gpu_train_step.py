@@ -299,3 +299,111 @@ def test_sharded_train_steps_match_the_unsharded_run(native, kind, nb, world):
                 b.free()
         for e in [ref] + engs:
             e.close()
+
+
+# ------------------------------------------------------------------ edge dropout on the device
+def _unique_batch(rng, V, R, n):
+    t = np.unique(np.stack([rng.randint(0, V, 3 * n), rng.randint(0, R, 3 * n), rng.randint(0, V, 3 * n)], 1), axis=0)
+    assert len(t) >= n
+    return np.ascontiguousarray(t[rng.permutation(len(t))[:n]].astype(np.int32))
+
+
+def test_device_edge_dropout_semantics(native):
+    """reference train.py:233-238: the message graph is a random subset of EXACTLY k batch edges, no repeats; degrees
+    are those of the kept edges (H8).  Here the draw runs on the device: exact k, rows of the batch in batch order,
+    a function of the seed, every edge equally likely; an injected keep mask is obeyed row for row; a forward pass on
+    the drawn graph is bitwise the forward pass on the same rows fed as a plain graph."""
+    V, R, d, L, nb, n = 150, 7, 16, 2, 4, 3000
+    rng = np.random.RandomState(3)
+    batch = _unique_batch(rng, V, R, n)
+    index_of = {tuple(r): i for i, r in enumerate(batch)}
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=n)
+    try:
+        eng.set_params(params)
+        bd = eng.to_device(batch)
+        draws = {}
+        for seed, keep in ((1, 1500), (1, 1500), (2, 1500), (7, 1), (7, n - 1), (9, 0), (9, n)):
+            eng.set_graph_dropout_device(bd, n, keep, seed=seed)
+            edges = eng.graph_edges()
+            assert edges.shape == (keep, 3)
+            idx = np.array([index_of[tuple(r)] for r in edges], dtype=np.int64)
+            assert len(set(idx.tolist())) == keep and (np.diff(idx) > 0).all()        # distinct batch rows, batch order
+            eng.sync()
+            np.testing.assert_array_equal(eng.read_buffer(native.BUF_INDEG), np.bincount(edges[:, 2], minlength=V))
+            np.testing.assert_array_equal(eng.read_buffer(native.BUF_OUTDEG), np.bincount(edges[:, 0], minlength=V))
+            draws.setdefault((seed, keep), []).append(idx)
+        a, b = draws[(1, 1500)]
+        assert np.array_equal(a, b) and not np.array_equal(a, draws[(2, 1500)][0])
+        # the drawn graph behaves exactly like the same rows fed directly
+        eng.set_graph_dropout_device(bd, n, 1500, seed=1)
+        eng.forward(train=False)
+        got = eng.codes()
+        eng.set_graph(batch[a])
+        eng.forward(train=False)
+        np.testing.assert_array_equal(got, eng.codes())
+        # injected set (how a test replays the reference's np.random.choice): obeyed row for row
+        mask = np.zeros(n, np.uint8)
+        mask[rng.choice(n, 1234, replace=False)] = 1
+        md = eng.to_device(mask)
+        eng.set_graph_dropout_device(bd, n, 1234, keep_mask=md)
+        np.testing.assert_array_equal(eng.graph_edges(), batch[mask.astype(bool)])
+        eng.set_graph_dropout_device(bd, n, 1233, keep_mask=md)                        # a mask with another count is refused
+        with pytest.raises(native.RgcnError):
+            eng.sync()
+        # uniformity: 400 edges, keep 100, 300 seeds -> every draw holds exactly 100, each edge ~ Binomial(300, 1/4)
+        small = eng.to_device(batch[:400])
+        counts = np.zeros(400, np.int64)
+        for seed in range(300):
+            eng.set_graph_dropout_device(small, 400, 100, seed=1000 + seed)
+            kept = eng.graph_edges()
+            counts[[index_of[tuple(r)] for r in kept]] += 1
+        assert counts.sum() == 300 * 100
+        assert counts.min() >= 40 and counts.max() <= 115, (counts.min(), counts.max())     # mean 75, sd 7.5: +-5 sd
+        half = counts[:200].sum() / float(counts.sum())
+        assert abs(half - 0.5) < 0.02                                                        # no positional bias
+        for b in (bd, md, small):
+            b.free()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_minibatch_step_equals_the_step_on_its_own_draws(native, prefetch):
+    """rgcn_train_step_minibatch_device (edge dropout + negatives + train step, one call) against the same three
+    pieces called one by one with the rows the dropout kernel drew: weights bitwise equal after three Adam steps; with
+    the graph of each step prepared beside the previous one (rgcn_prefetch_graph_dropout_device) as well"""
+    V, R, d, L, nb, n, rate = 120, 6, 20, 2, 4, 800, 3
+    rng = np.random.RandomState(5)
+    batches = [_unique_batch(rng, V, R, n) for _ in range(2)]
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    N = n * (rate + 1)
+    out = []
+    for fused in (True, False):
+        eng = native.Engine(V, R, d, L, "block", nb, max_edges=n)
+        try:
+            eng.set_params(params)
+            eng.decoder_reserve(N)
+            eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
+            bds = [eng.to_device(b) for b in batches]
+            xd, yd = eng.alloc(12 * N), eng.alloc(4 * N)
+            gd = eng.alloc(12 * n)
+            for step in range(3):
+                bd, keep, eseed, nseed, seed = bds[step % 2], 300 + 50 * step, 40 + step, 90 + step, 7 + step
+                if fused:
+                    eng.train_step_minibatch_device(bd, n, keep, eseed, rate, nseed, xd, yd, seed=seed, reg_param=0.01)
+                    if prefetch and step < 2:
+                        eng.prefetch_graph_dropout_device(bds[(step + 1) % 2], n, 300 + 50 * (step + 1), 40 + step + 1)
+                else:
+                    eng.set_graph_dropout_device(bd, n, keep, seed=eseed)
+                    eng.copy_to_device(gd, eng.graph_edges())
+                    eng.negative_sample_device(bd, n, rate, nseed, xd, yd)
+                    eng.train_step_device(gd, keep, xd, yd, N, seed=seed, reg_param=0.01)
+                assert np.isfinite(eng.loss())
+            out.append({k: eng.get_param(k) for k in eng.param_names})
+            for b in bds + [xd, yd, gd]:
+                b.free()
+        finally:
+            eng.close()
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
