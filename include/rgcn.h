@@ -373,20 +373,6 @@ int32_t     rgcn_profile_count(rgcn_ctx* ctx); /* synchronises, aggregates; numb
 rgcn_status rgcn_profile_get(rgcn_ctx* ctx, int32_t i, char* name, int32_t name_cap, int64_t* calls,
                              double* total_ms, double* alg_bytes, double* alg_flops);
 
-/* ---- debugging aids used by the GPU parity tests ---------------------------------------------- */
-/* C[M,N] = op(A) . op(B) through the library's fp32-MFMA GEMM.  trans_a == 0: A is [M,K] row-major,
- * else A is [K,M] row-major (used transposed); trans_b == 0: B is [K,N], else [N,K].
- * split_k == 0 picks the split the encoder would use; > 1 forces that many K slabs. */
-rgcn_status rgcn_debug_gemm(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b, int32_t M, int32_t N,
-                            int32_t K, int32_t split_k, const float* a_host, const float* b_host,
-                            float* c_host);
-
-/* Same contraction on device copies of the operands, `iters` back-to-back launches timed with HIP
- * events on the context's stream; *avg_ms = mean time of one product (incl. the split-K reduce). */
-rgcn_status rgcn_debug_gemm_time(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b, int32_t M, int32_t N,
-                                 int32_t K, int32_t split_k, int32_t iters, const float* a_host,
-                                 const float* b_host, float* avg_ms);
-
 #ifdef __cplusplus
 }
 #endif

@@ -117,10 +117,14 @@ _SIGS = {
     "rgcn_profile_count": (C.c_int32, [_P]),
     "rgcn_profile_get": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+# librgcn_devtools.so only (include/rgcn_devtools.h)
+_DEVTOOLS_SIGS = {
     "rgcn_debug_gemm": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rgcn_debug_gemm_time": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, _P, _P, C.POINTER(C.c_float)]),
 }
+_lib_devtools = None
 
 
 def exported_symbols():
@@ -128,9 +132,28 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
-def load_library(path=None):
-    """dlopen librgcn.so and attach prototypes.  Raises ImportError (never falls back) if missing."""
-    global _lib
+def exported_devtools_symbols():
+    return sorted(_DEVTOOLS_SIGS)
+
+
+def load_library(path=None, devtools=False):
+    """dlopen librgcn.so and attach prototypes.  Raises ImportError (never falls back) if missing.
+    devtools=True: librgcn_devtools.so, the same sources plus the stand-alone GEMM entry points."""
+    global _lib, _lib_devtools
+    if devtools:
+        if _lib_devtools is None or path is not None:
+            p = path or os.path.join(os.path.dirname(LIB_PATH), "librgcn_devtools.so")
+            if not os.path.exists(p):
+                raise ImportError("%s not found: python -m relationprediction_amd.build makes it" % p)
+            lib = C.CDLL(p, mode=C.RTLD_LOCAL)
+            for name, (res, args) in list(_SIGS.items()) + list(_DEVTOOLS_SIGS.items()):
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            if path is not None:
+                return lib
+            _lib_devtools = lib
+        return _lib_devtools
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
@@ -215,8 +238,8 @@ class Engine:
     """One rgcn_ctx: the encoder (input layer + L relational graph-convolution layers) on one GPU."""
 
     def __init__(self, num_entities, num_relations, dim, num_layers, kind, num_bases, keep_prob=0.8,
-                 norm_mode="intended", max_edges=0, device=0, rank=0, world=1):
-        self.lib = load_library()
+                 norm_mode="intended", max_edges=0, device=0, rank=0, world=1, devtools=False):
+        self.lib = load_library(devtools=devtools)
         self.ctx = None
         cfg = RgcnConfig()
         cfg.abi_version = ABI_VERSION

@@ -20,10 +20,15 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librgcn.so")
+# the same sources with -DRGCN_DEVTOOLS: adds the stand-alone GEMM entry points of include/rgcn_devtools.h for
+# tools/ and the dense-contraction tests; the product library has none of them
+LIB_DEVTOOLS = os.path.join(LIBDIR, "librgcn_devtools.so")
 ARCH = "gfx950"
 SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h")]
+HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h"),
+           os.path.join(ROOT, "include", "rgcn_devtools.h")]
+DEVTOOLS_SOURCES = ["rgcn_api.hip"]       # the only translation unit the flag changes
 # No packed-FP32 VALU instructions anywhere in the library: on gfx950 a v_pk_fma_f32 (and kin) issued
 # by a wave that shares a CU with waves issuing v_mfma_f32_32x32x16_bf16 returns wrong low halves
 # (reproducer: tools/mfma_corun.hip).  The encoder runs its HBM-bound kernels on side
@@ -87,20 +92,22 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
-    for src in SOURCES:
+    for src in SOURCES + [d + "@devtools" for d in DEVTOOLS_SOURCES]:
+        dev = src.endswith("@devtools")
+        src = src.replace("@devtools", "")
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".devtools.o" if dev else ".o"))
         stamp = obj + ".sha"
-        dig = _digest([sp] + HEADERS)
+        dig = _digest([sp] + HEADERS) + ("+devtools" if dev else "")
         fresh = (not force and os.path.exists(obj) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
-        jobs.append((sp, obj, stamp, dig, fresh))
+        jobs.append((sp, obj, stamp, dig, fresh, dev))
 
     def compile_one(job):
-        sp, obj, stamp, dig, fresh = job
+        sp, obj, stamp, dig, fresh, dev = job
         if fresh:
             return None
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-DRGCN_DEVTOOLS"] if dev else []) + ["-c", sp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (sp, r.stderr[-4000:]))
@@ -113,12 +120,17 @@ def build(force=False, verbose=False):
     for o in outs:
         if o:
             sys.stderr.write(o)
-    if force or not os.path.exists(LIB) or any(not j[4] for j in jobs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + [j[1] for j in jobs] + ["-ldl"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
-        check_no_packed_fp32(LIB)
+    product = [j for j in jobs if not j[5]]
+    devobj = {os.path.basename(j[0]): j[1] for j in jobs if j[5]}
+    stale = any(not j[4] for j in jobs)
+    for lib, objs in ((LIB, [j[1] for j in product]),
+                      (LIB_DEVTOOLS, [devobj.get(os.path.basename(j[0]), j[1]) for j in product])):
+        if force or stale or not os.path.exists(lib):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+            check_no_packed_fp32(lib)
     return LIB
 
 

@@ -66,7 +66,6 @@ struct XArgs {
   int tiles_m, tiles_n, splits;
   int swizzle;
   int vecC;
-  int ablate;   // timing experiments only (tools/gemm_modes.py): 1 no in-loop global loads, 2 no split/store, 4 no epilogue, 8 no scheduling groups
 };
 
 constexpr int BM = 128, BN = 128, BK = 16, NTH = 256;
@@ -224,9 +223,7 @@ __device__ __forceinline__ bf16x8 load_frag(const uint32_t* __restrict__ plane, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// ABL: compile-time ablations for tools/gemm_modes.py (1 no in-loop global loads, 2 no split/store,
-// 8 no fragment reads, 16 no barrier, 32 no MFMA, 64 no conversion / LDS store of operand B); results are garbage, only the timing means anything.
-template <bool A_KC, bool B_KC, bool VEC, int TERMS, int ABL = 0>
+template <bool A_KC, bool B_KC, bool VEC, int TERMS>
 __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   constexpr int PA = A_KC ? KC_PLANE : RC_PLANE, PB = B_KC ? KC_PLANE : RC_PLANE;
   constexpr int TA = 3 * PA, TB = 3 * PB;
@@ -318,34 +315,19 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   auto step = [&](int kt, auto parity, auto walk) {
     constexpr int P = decltype(parity)::value;
     constexpr bool WALK = decltype(walk)::value;
-    if constexpr (!(ABL & 1)) {
-      if constexpr (WALK) gwalk(ra[P], rb[P]); else gload(ks + (kt + 2) * BK, ra[P], rb[P]);
-    }
+    if constexpr (WALK) gwalk(ra[P], rb[P]); else gload(ks + (kt + 2) * BK, ra[P], rb[P]);
     const uint32_t* a_lds = lds + P * (TA + TB);
     const uint32_t* b_lds = a_lds + TA;
     uint32_t* nxt = lds + (1 - P) * (TA + TB);
     bf16x8 fa[2][3], fb[2][3];
-    if constexpr (ABL & 8) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          u32x4 zz = {0u, 0u, 0u, 0u};
-          asm volatile("" : "+v"(zz));
-          fa[i][pl] = __builtin_bit_cast(bf16x8, zz);
-          asm volatile("" : "+v"(zz));
-          fb[i][pl] = __builtin_bit_cast(bf16x8, zz);
-        }
-    } else {
+      for (int pl = 0; pl < 3; ++pl) fa[i][pl] = load_frag<A_KC>(a_lds + pl * PA, wm + 32 * i + li, h);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fa[i][pl] = load_frag<A_KC>(a_lds + pl * PA, wm + 32 * i + li, h);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[j][pl] = load_frag<B_KC>(b_lds + pl * PB, wn + 32 * j + li, h);
-    }
+      for (int pl = 0; pl < 3; ++pl) fb[j][pl] = load_frag<B_KC>(b_lds + pl * PB, wn + 32 * j + li, h);
     __builtin_amdgcn_sched_barrier(0);
     // partial products from the smallest to the largest; plane 0 = hi, 1 = mid, 2 = lo.  Behind MFMA m
     // goes conversion chunk m of the NEXT tile (24 chunks; order pinned by the scheduling fences).
@@ -358,18 +340,14 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     auto weave = [&](auto mi) {
       constexpr int m = decltype(mi)::value;
       constexpr int t = NP - TERMS + m / 4, i = (m / 2) % 2, j = m % 2;
-      if constexpr (!(ABL & 32))
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_[t]], fb[j][pb_[t]], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_[t]], fb[j][pb_[t]], acc[i][j], 0, 0, 0);
       constexpr int c0 = m * PER < 24 ? m * PER : 24, c1 = (m + 1) * PER < 24 ? (m + 1) * PER : 24;
-      if constexpr (!(ABL & 2)) {
-        split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt);
-        if constexpr (!(ABL & 64))    // 64: operand B costs nothing (upper bound of what a pre-split W could save)
-          split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
-      }
+      split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt);
+      split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
       __builtin_amdgcn_sched_barrier(0);
     };
     static_for<0, NM>(weave);
-    if constexpr (!(ABL & 16)) lds_barrier();
+    lds_barrier();
   };
 
   if (nkt > 0) {
@@ -394,10 +372,6 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     if (kt + 1 < nkt) step(kt + 1, I1{}, std::false_type{});
   }
 
-  if (g.ablate & 4) {
-    if (acc[0][0][0] == 123.456f) g.C[0] = 1.f;   // keep the accumulators live
-    return;
-  }
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
   float* C = g.C + (size_t)z * g.M * g.ldc;
   if (g.vecC) {
@@ -452,10 +426,10 @@ constexpr size_t lds_bytes(bool a_kc, bool b_kc) {
   return tiles > epi ? tiles : epi;
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TERMS, int ABL = 0>
+template <bool A_KC, bool B_KC, bool VEC, int TERMS>
 hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
   constexpr size_t bytes = lds_bytes(A_KC, B_KC);
-  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS, ABL>;
+  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS>;
   static bool configured = false;     // per instantiation; contexts are single-threaded per process
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -487,25 +461,6 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
   g.k_per_split = k_per_split; g.splits = splits; g.swizzle = swizzle; g.vecC = vecC;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
-  static const int ablate = getenv("RGCN_GEMM_ABLATE") ? atoi(getenv("RGCN_GEMM_ABLATE")) : 0;
-  g.ablate = ablate;
-
-  if (terms == 6 && vec && a_kc && b_kc && (ablate & ~4)) {   // timing experiments on the NT form only
-    switch (ablate & ~4) {
-      case 1: return launch_one<true, true, true, 6, 1>(c, g);
-      case 2: return launch_one<true, true, true, 6, 2>(c, g);
-      case 3: return launch_one<true, true, true, 6, 3>(c, g);
-      case 8: return launch_one<true, true, true, 6, 8>(c, g);
-      case 11: return launch_one<true, true, true, 6, 11>(c, g);
-      case 16: return launch_one<true, true, true, 6, 16>(c, g);
-      case 27: return launch_one<true, true, true, 6, 27>(c, g);
-      case 32: return launch_one<true, true, true, 6, 32>(c, g);
-      case 59: return launch_one<true, true, true, 6, 59>(c, g);
-      case 64: return launch_one<true, true, true, 6, 64>(c, g);
-
-      default: break;
-    }
-  }
   if (terms == 9) return vec ? launch_form<true, 9>(c, a_kc, b_kc, g) : launch_form<false, 9>(c, a_kc, b_kc, g);
   if (terms == 3) return vec ? launch_form<true, 3>(c, a_kc, b_kc, g) : launch_form<false, 3>(c, a_kc, b_kc, g);
   return vec ? launch_form<true, 6>(c, a_kc, b_kc, g) : launch_form<false, 6>(c, a_kc, b_kc, g);

@@ -42,7 +42,6 @@ struct GemmArgs {
   int tiles_m, tiles_n, splits;
   int swizzle;       // XCD-aware workgroup remap
   int vecC;          // 16-byte row-contiguous stores legal (aligned C, ldc % 4 == 0, N % 4 == 0)
-  int ablate;        // timing experiments only (tools/gemm_sweep.py): 1 no in-loop global loads, 2 no barrier, 4 no stores
 };
 
 template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
@@ -179,7 +178,7 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
-    if (more && !(g.ablate & 1)) {   // next tile's global loads fly under this tile's MFMAs
+    if (more) {   // next tile's global loads fly under this tile's MFMAs
       load_tile<A_KC, BM, BK, NT, PA, VEC>(g.A, g.zeros, g.lda, g.M, m0, ks + (kt + 1) * BK, ke, ra);
       load_tile<B_KC, BN, BK, NT, PB, VEC>(g.B, g.zeros, g.ldb, g.N, n0, ks + (kt + 1) * BK, ke, rb);
     }
@@ -200,17 +199,12 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
     }
-    if (more && !(g.ablate & 8)) {
+    if (more) {
       store_tile<A_KC, BM, BK, NT, PA>(lds + (cur ^ 1) * (TA + TB), ra);
       store_tile<B_KC, BN, BK, NT, PB>(lds + (cur ^ 1) * (TA + TB) + TA, rb);
     }
-    if (!(g.ablate & 2)) __syncthreads();
+    __syncthreads();
   }
-  if (g.ablate & 4) {
-    if (acc[0][0][0] == 123.456f) g.C[0] = 1.f;   // keep the accumulators live
-    return;
-  }
-
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
   float* C = g.C + (size_t)z * g.M * g.ldc;   // slab z (ldc == N for slabs)
   if (g.vecC) {
@@ -340,8 +334,6 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
   const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N);
   g.swizzle = swizzle;
-  static const int ablate = env_int("RGCN_GEMM_ABLATE", 0);
-  g.ablate = ablate;
   g.zeros = c->zeros;
   if (split_k < 1) split_k = 1;
   int kps = (K + split_k - 1) / split_k;

@@ -7,6 +7,9 @@
 #include <new>
 
 #include "rgcn_internal.h"
+#ifdef RGCN_DEVTOOLS
+#include "../../include/rgcn_devtools.h"
+#endif
 
 namespace rgcn {
 
@@ -1318,6 +1321,7 @@ rgcn_status rgcn_profile_get(rgcn_ctx* c, int32_t i, char* name, int32_t name_ca
   return RGCN_OK;
 }
 
+#ifdef RGCN_DEVTOOLS
 rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
                             int32_t split_k, const float* a_host, const float* b_host, float* c_host) {
   RGCN_NEED(c);
@@ -1377,5 +1381,7 @@ rgcn_status rgcn_debug_gemm_time(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M,
   if (C) (void)hipFree(C);
   return s;
 }
+
+#endif  // RGCN_DEVTOOLS
 
 }  // extern "C"

@@ -19,6 +19,7 @@
 
 struct rgcn_sampler {
   int64_t n_edges = 0;
+  int64_t n_with_edges = 0;                     // vertices with at least one incident edge
   int32_t V = 0;
   std::vector<int32_t> src, dst;
   std::vector<int64_t> adj_ptr;                 // [V+1]
@@ -31,6 +32,13 @@ struct rgcn_sampler {
   std::vector<int64_t> pos[2];                  // [E] position of the edge's subject- / object-side entry
   std::vector<uint8_t> seen, picked;
   std::vector<int64_t> fen;                     // Fenwick tree over seen[v] ? alive[v] : 0
+  int64_t fen_sum = 0;                          // its total, kept beside it
+  // The per-sample state is restored, not rebuilt: a sample touches O(sample_size) adjacency entries and vertices of a
+  // graph that may hold ten times as many edges, so every change is logged and undone afterwards.
+  bool pristine = false;                        // adj_edge / adj_side / pos / alive / seen / picked / fen are in their initial state
+  struct Undo { int64_t p; int32_t edge; uint8_t side; };
+  std::vector<Undo> undo;
+  std::vector<int32_t> touched;                 // vertices whose alive / seen changed
 };
 
 namespace {
@@ -60,13 +68,11 @@ struct Rng {                                    // splitmix64-seeded xoshiro256*
   }
 };
 
-void fen_add(std::vector<int64_t>& f, int32_t V, int32_t i, int64_t delta) {
+void fen_add(rgcn_sampler* s, int32_t i, int64_t delta) {
+  int64_t* f = s->fen.data();
+  const int32_t V = s->V;
   for (int32_t k = i + 1; k <= V; k += k & -k) f[k] += delta;
-}
-int64_t fen_total(const std::vector<int64_t>& f, int32_t V) {
-  int64_t t = 0;
-  for (int32_t k = V; k > 0; k -= k & -k) t += f[k];
-  return t;
+  s->fen_sum += delta;
 }
 // smallest index whose prefix sum exceeds r (0 <= r < total)
 int32_t fen_find(const std::vector<int64_t>& f, int32_t V, int64_t r) {
@@ -82,19 +88,41 @@ int32_t fen_find(const std::vector<int64_t>& f, int32_t V, int64_t r) {
 void remove_entry(rgcn_sampler* s, int32_t v, int64_t p) {
   const int64_t base = s->adj_ptr[v], last = base + s->alive[v] - 1;
   if (p != last) {                              // move the last live entry into the hole
+    s->undo.push_back({p, s->adj_edge[p], s->adj_side[p]});
+    s->undo.push_back({last, s->adj_edge[last], s->adj_side[last]});
     s->adj_edge[p] = s->adj_edge[last];
     s->adj_side[p] = s->adj_side[last];
     s->pos[s->adj_side[p]][s->adj_edge[p]] = p;
   }
   s->alive[v] -= 1;
-  if (s->seen[v]) fen_add(s->fen, s->V, v, -1);
+  if (s->seen[v]) fen_add(s, v, -1);
 }
 
 void touch(rgcn_sampler* s, int32_t v) {
   if (!s->seen[v]) {
     s->seen[v] = 1;
-    if (s->alive[v]) fen_add(s->fen, s->V, v, s->alive[v]);
+    s->touched.push_back(v);
+    if (s->alive[v]) fen_add(s, v, s->alive[v]);
   }
+}
+
+// back to the initial state: undo the adjacency moves in reverse, then the per-vertex / per-edge marks
+void restore(rgcn_sampler* s, const int32_t* picked_ids, int64_t n_picked) {
+  for (size_t k = s->undo.size(); k-- > 0;) {
+    const rgcn_sampler::Undo& u = s->undo[k];
+    s->adj_edge[u.p] = u.edge;
+    s->adj_side[u.p] = u.side;
+    s->pos[u.side][u.edge] = u.p;
+  }
+  s->undo.clear();
+  for (int32_t v : s->touched) {
+    s->alive[v] = (int32_t)(s->adj_ptr[v + 1] - s->adj_ptr[v]);
+    s->seen[v] = 0;
+  }
+  s->touched.clear();
+  for (int64_t i = 0; i < n_picked; ++i) s->picked[picked_ids[i]] = 0;
+  std::memset(s->fen.data(), 0, s->fen.size() * sizeof(int64_t));
+  s->fen_sum = 0;
 }
 
 }  // namespace
@@ -152,23 +180,32 @@ rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* s, int64_t sample_size,
   if (sample_size > s->n_edges) return RGCN_ERR_INVALID;
   const int32_t V = s->V;
   try {
-    s->adj_edge = s->adj_edge0;
-    s->adj_side = s->adj_side0;
-    s->alive.resize(V);
-    for (int32_t v = 0; v < V; ++v) s->alive[v] = (int32_t)(s->adj_ptr[v + 1] - s->adj_ptr[v]);
-    for (size_t p = 0; p < s->adj_edge.size(); ++p) s->pos[s->adj_side[p]][s->adj_edge[p]] = (int64_t)p;
-    s->seen.assign(V, 0);
-    s->picked.assign((size_t)s->n_edges, 0);
-    s->fen.assign((size_t)V + 1, 0);
+    if (!s->pristine) {                         // first sample: build the working state once
+      s->adj_edge = s->adj_edge0;
+      s->adj_side = s->adj_side0;
+      s->alive.resize(V);
+      s->n_with_edges = 0;
+      for (int32_t v = 0; v < V; ++v) {
+        s->alive[v] = (int32_t)(s->adj_ptr[v + 1] - s->adj_ptr[v]);
+        s->n_with_edges += s->alive[v] > 0;
+      }
+      for (size_t p = 0; p < s->adj_edge.size(); ++p) s->pos[s->adj_side[p]][s->adj_edge[p]] = (int64_t)p;
+      s->seen.assign(V, 0);
+      s->picked.assign((size_t)s->n_edges, 0);
+      s->fen.assign((size_t)V + 1, 0);
+      s->fen_sum = 0;
+      s->pristine = true;
+    }
+    s->undo.reserve(4 * (size_t)sample_size);
+    s->touched.reserve(2 * (size_t)sample_size + 16);
   } catch (const std::bad_alloc&) {
     return RGCN_ERR_NOMEM;
   }
   Rng rng(seed);
-  int64_t with_free = 0;                        // vertices that still have free edge ends
-  for (int32_t v = 0; v < V; ++v) with_free += s->alive[v] > 0;
+  int64_t with_free = s->n_with_edges;          // vertices that still have free edge ends
   for (int64_t i = 0; i < sample_size; ++i) {
     int32_t v;
-    const int64_t total = fen_total(s->fen, V);
+    const int64_t total = s->fen_sum;
     if (total > 0) {
       v = fen_find(s->fen, V, (int64_t)rng.below((uint64_t)total));
     } else {                                    // nothing touched has free edges: uniform over vertices that do
@@ -192,6 +229,7 @@ rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* s, int64_t sample_size,
     touch(s, a);
     touch(s, b);
   }
+  restore(s, out_ids, sample_size);
   return RGCN_OK;
 }
 

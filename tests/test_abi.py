@@ -43,9 +43,28 @@ def test_binding_matches_header(lib_path):
     assert ctypes.sizeof(_native.RgcnConfig) == 64
 
 
+def test_experiment_hooks_live_in_the_devtools_build_only(lib_path):
+    """the product library exports nothing but include/rgcn.h; the stand-alone GEMM entry points of
+    include/rgcn_devtools.h exist in librgcn_devtools.so (-DRGCN_DEVTOOLS) only, and no ablation switch is left in
+    the product sources"""
+    from relationprediction_amd import _native, build
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgcn_devtools.h")).read(), flags=re.S)
+    dev = sorted(set(re.findall(r"\b(rgcn_[a-z_0-9]+)\s*\(", text)))
+    assert dev == _native.exported_devtools_symbols() and dev
+    product, devtools = ctypes.CDLL(lib_path), ctypes.CDLL(build.LIB_DEVTOOLS)
+    for s in dev:
+        assert not hasattr(product, s), "product library exports %s" % s
+        assert hasattr(devtools, s)
+    for s in declared_symbols():
+        assert hasattr(devtools, s)
+    for name in os.listdir(build.CSRC):
+        src = open(os.path.join(build.CSRC, name)).read()
+        assert "RGCN_GEMM_ABLATE" not in src and "ablate" not in src, name
+
+
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "rgcn.h"\nint main(void){ rgcn_config c; (void)c; return sizeof(rgcn_config) == 64 ? 0 : 1; }\n')
+    src.write_text('#include "rgcn.h"\n#include "rgcn_devtools.h"\nint main(void){ rgcn_config c; (void)c; return sizeof(rgcn_config) == 64 ? 0 : 1; }\n')
     exe = tmp_path / "t"
     import subprocess
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),

@@ -82,7 +82,7 @@ def test_gemm_forms(native, M, N, K, form, mode):
     A = rng.randn(M, K).astype(np.float32)
     B = rng.randn(K, N).astype(np.float32)
     ref = A.astype(np.float64) @ B.astype(np.float64)
-    eng = native.Engine(16, 2, 8, 1, "block", 2, max_edges=4)
+    eng = native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True)   # rgcn_debug_gemm: devtools build only
     try:
         eng.set_gemm_mode(mode)
         if form == "NN":
@@ -111,7 +111,7 @@ def test_gemm_modes_are_fp32_accurate(native):
     wide = (rng.randn(V, d) * np.exp(rng.uniform(-14, 14, (V, d)))).astype(np.float32)
     cases = {"NN": (H, W, False, False), "NT": (D, W, False, True), "TN": (H, D, True, False),
              "NN wide": (wide, W, False, False)}
-    eng = native.Engine(V, 2, d, 1, "block", 100, max_edges=4)
+    eng = native.Engine(V, 2, d, 1, "block", 100, max_edges=4, devtools=True)
     try:
         for name, (a, b, ta, tb) in cases.items():
             a64 = (a.T if ta else a).astype(np.float64)

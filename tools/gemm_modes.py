@@ -16,7 +16,7 @@ forms = {
     "NT dS.Wt": (False, True, V, D, D),
     "TN Ht.dS": (True, False, D, D, V),
 }
-eng = nat.Engine(64, 3, 20, 1, "block", 4, max_edges=16)
+eng = nat.Engine(64, 3, 20, 1, "block", 4, max_edges=16, devtools=True)
 if os.environ.get("RGCN_PROBE_ONLY"):
     # NT form at one and two tiles per CU (mode 6): the lone-workgroup critical path under RGCN_GEMM_ABLATE
     eng.set_gemm_mode(6)

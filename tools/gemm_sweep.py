@@ -16,7 +16,7 @@ from relationprediction_amd import _native
 V, d = 14541, 500
 rng = np.random.RandomState(0)
 H = rng.randn(V, d).astype(np.float32); W = rng.randn(d, d).astype(np.float32); D = rng.randn(V, d).astype(np.float32)
-eng = _native.Engine(V, 4, d, 1, "block", 100, max_edges=16)
+eng = _native.Engine(V, 4, d, 1, "block", 100, max_edges=16, devtools=True)
 out = {}
 ref = H[:256].astype(np.float64) @ W.astype(np.float64)
 got = eng.debug_gemm(H[:256], W)

@@ -12,7 +12,7 @@ rng = np.random.RandomState(0)
 H = np.maximum(rng.randn(V, d), 0).astype(np.float32)
 W = (rng.randn(d, d) * 0.19).astype(np.float32)
 D = (rng.randn(V, d) * 1e-3).astype(np.float32)
-eng = _native.Engine(V, 2, d, 1, "block", 100, max_edges=4)
+eng = _native.Engine(V, 2, d, 1, "block", 100, max_edges=4, devtools=True)
 flops = 2.0 * V * d * d
 for mode in (6, 9, 0):
     eng.set_gemm_mode(mode)
