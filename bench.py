@@ -229,12 +229,16 @@ def measure(workload, args, rk, steps, warmup, full):
         if steps % 2:
             sys.exit("--hipgraph: --steps must be even (one launch = two steps)")
         # steady state of the pipelined loop as ONE graph: step on A beside the preparation of B, then the reverse
-        eng.prefetch_graph_device(graphs[0], E_g)
+        # (RGCN_BENCH_GRAPH_NOPF=1, an A/B knob: no prefetches in the graph, every step prepares its own graph in line)
+        in_graph_prefetch = os.environ.get("RGCN_BENCH_GRAPH_NOPF") != "1"
+        if in_graph_prefetch:
+            eng.prefetch_graph_device(graphs[0], E_g)
         eng.sync()
         eng.capture_begin()
         for i in (0, 1):
             eng.step_device(graphs[i], E_g, dc_dev, train=True, seed=2000 + i)
-            eng.prefetch_graph_device(graphs[1 - i], E_g)
+            if in_graph_prefetch:
+                eng.prefetch_graph_device(graphs[1 - i], E_g)
         graph_id = eng.capture_end()
         plain_run = run
 

@@ -1049,6 +1049,12 @@ rgcn_status rgcn_capture_begin(rgcn_ctx* c) {
   c->cap_pf_forked = false;
   RGCN_HIP(c, hipStreamBeginCapture(c->main_stream, hipStreamCaptureModeRelaxed));
   c->capturing = true;
+  // A captured step is recorded as ONE chain on the main stream (only the prefetch of the next graph forks off):
+  // the replayed graph pays more than streams do for every cross-stream edge (measured, profiles/r02_hipgraph_ab.log:
+  // 0.687 ms per step with the side streams captured, 0.634-0.640 as a chain, 0.614-0.631 stream-launched), and
+  // the side streams buy the stream-launched step under 3 %.
+  c->use_aux_before_capture = c->use_aux;
+  c->use_aux = false;
   hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, c->main_stream, c->replay_counter);
   return RGCN_OK;
 }
@@ -1065,6 +1071,7 @@ rgcn_status rgcn_capture_end(rgcn_ctx* c, int32_t* graph_id) {
   hipGraph_t graph = nullptr;
   const hipError_t e2 = hipStreamEndCapture(c->main_stream, &graph);
   c->capturing = false;
+  c->use_aux = c->use_aux_before_capture;
   // events last recorded inside the capture are unusable outside it: give them a fresh, ordinary record
   (void)hipEventRecord(c->ev_fork, c->main_stream);
   (void)hipEventRecord(c->ev_step_begin, c->main_stream);

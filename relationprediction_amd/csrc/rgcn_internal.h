@@ -264,6 +264,7 @@ struct rgcn_ctx {
   int bwd_layer = 0;                     // next layer the backward pass will process (L..1, 0 = done)
   // hipGraph capture (rgcn_capture_begin / _end / rgcn_graph_launch)
   bool capturing = false;
+  bool use_aux_before_capture = true;    // side-stream setting to restore when the capture ends
   bool cap_pf_forked = false;            // the prefetch stream has joined the capture and must be joined back
   uint64_t* replay_counter = nullptr;    // device counter bumped at the start of every captured graph
   hipEvent_t ev_step_begin = nullptr;    // recorded on the main stream where a step starts (capture: fork point of the prefetch)
