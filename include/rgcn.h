@@ -352,6 +352,14 @@ rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises *
  * With overlap off every kernel runs alone on the main stream: per-kernel durations are exclusive. */
 rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
 
+/* The self-loop GEMM with the combine step as its epilogue (default OFF; RGCN_FUSE=1 in the environment turns it on
+ * at create): H' = relu(dropout(H.W_self) + sum of the row's messages) leaves ONE kernel and the product never
+ * travels to HBM and back (58 MB less per layer pass at FB15k-237 size); likewise the backward (dS.W_self^T + message
+ * gradients) * relu'.  Block kind, one GPU, split arithmetic, minibatch-sized graphs; everything else runs the
+ * two-kernel form.  Both forms give bitwise the same result; on MI355X the fused kernel is the slower one (87-89 us
+ * against 80-83 for the pair), hence the default. */
+rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t on);
+
 /* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.
  *   6 : (default) every fp32 operand is split exactly into three bf16 numbers hi + mid + lo (round to
  *       nearest + exact residual, twice) and the product is accumulated in fp32 from 6 of the 9 partial

@@ -112,6 +112,7 @@ _SIGS = {
     "rgcn_timer_stop": (C.c_int32, [_P, C.POINTER(C.c_float)]),
     "rgcn_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "rgcn_set_gemm_mode": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_set_fusion": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_reset": (C.c_int32, [_P]),
     "rgcn_profile_count": (C.c_int32, [_P]),
@@ -598,6 +599,9 @@ class Engine:
 
     def set_overlap(self, on=True):
         self._check(self.lib.rgcn_set_overlap(self.ctx, 1 if on else 0))
+
+    def set_fusion(self, on=True):
+        self._check(self.lib.rgcn_set_fusion(self.ctx, 1 if on else 0))
 
     def set_gemm_mode(self, mode):
         """0 = fp32 MFMA, 9 / 6 = exact bf16 operand split with 9 / 6 partial products (include/rgcn.h)."""

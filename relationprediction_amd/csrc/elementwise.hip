@@ -14,12 +14,7 @@ namespace rgcn {
 
 namespace {
 
-__device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
-  if (ds.mode == DROP_NONE) return 1.0f;
-  if (ds.mode == DROP_RNG)
-    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
-  return ds.mask[idx] ? ds.inv_keep : 0.0f;
-}
+__device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) { return drop_factor(ds, idx); }
 
 template <int VEC>
 struct VecT;
@@ -75,6 +70,9 @@ __device__ __forceinline__ void combine_epilogue(const CombineArgs& a, size_t of
 // dropout(base) + add for one vector of one row
 template <int VEC>
 __device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, size_t off, float (&acc)[VEC]) {
+  // no fused multiply-add across "dropout scale, then add": the GEMM's fused epilogue computes the same expression
+  // and both must round alike (the two paths are held bitwise equal by tests/test_gpu_parity.py)
+#pragma clang fp contract(off)
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
   if (a.base != nullptr && v >= a.row_lo && v < a.row_hi) {

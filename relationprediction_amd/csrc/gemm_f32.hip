@@ -324,7 +324,7 @@ int env_int(const char* name, int dflt) {
 
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k) {
+                     int split_k, const GemmEpilogue* epi) {
   if (M <= 0 || N <= 0) return RGCN_OK;
   if (a_kc == false && b_kc == true) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "gemm TT form not instantiated");
   static const int variant = env_int("RGCN_GEMM_VARIANT", 0);     // tuning knob (tools/gemm_sweep.py)
@@ -349,13 +349,16 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   } else {
     g.C = C; g.ldc = ldc;
   }
-  static const int epi = env_int("RGCN_GEMM_EPILOGUE", 1);
-  g.vecC = (epi && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
+  static const int staged_store = env_int("RGCN_GEMM_EPILOGUE", 1);
+  g.vecC = (staged_store && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
   {
-    ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * N * K);
+    ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N) + (epi ? epi->alg_extra_bytes : 0.0),
+                 2.0 * M * N * K);
+    if (epi && epi->mode != 0 && (c->gemm_mode == 0 || slabs || !vec || !g.vecC || ldc != N))
+      RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "internal: fused GEMM epilogue outside its domain");
     if (c->gemm_mode != 0) {
       RGCN_HIP(c, gemm_bf16x3_launch(c, c->gemm_mode, a_kc, b_kc, vec, M, N, K, A, lda, B, ldb, g.C, g.ldc,
-                                     g.k_per_split, g.splits, g.swizzle, g.vecC));
+                                     g.k_per_split, g.splits, g.swizzle, g.vecC, epi));
     } else switch (variant) {
       case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
       case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;

@@ -476,7 +476,8 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   {
     ProfScope ps(c, "prep_ptrs", 8.0 * (V + 2 * R) + 4.0 * M, 0);
     hipLaunchKernelGGL(k_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, g.keyv_s, g.keyr_s,
-                       g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows, g.nlong, g.long_cap,
+                       g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows,
+                       g.nlong, g.long_cap,
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
                        g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr);
   }

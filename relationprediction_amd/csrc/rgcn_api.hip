@@ -288,6 +288,11 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   {
     const char* e = getenv("RGCN_STREAMS");
     c->use_aux = !(e && atoi(e) == 0);
+    // Off by default: measured on MI355X (profiles/r02_fused_layer_ab.log) the fused kernel takes 87-89 us where GEMM +
+    // combine take 80-83 -- all workgroups reach the gather epilogue at once, with 8 waves per CU where k_combine runs
+    // 32 -- although it moves 58 MB less per layer pass.  RGCN_FUSE=1 / rgcn_set_fusion turn it on.
+    const char* fu = getenv("RGCN_FUSE");
+    c->fuse = fu && atoi(fu) != 0;
     const char* m = getenv("RGCN_GEMM_MODE");
     const int mode = m ? atoi(m) : 6;
     c->gemm_mode = (mode == 0 || mode == 3 || mode == 6 || mode == 9) ? mode : 6;
@@ -417,6 +422,12 @@ static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_
   return input_forward(c);
 }
 
+// The self-loop GEMM takes the combine as its epilogue: block kind, one GPU, split arithmetic (the fp32-MFMA kernel
+// keeps the two-kernel form), 16-byte rows, minibatch scale (no giant rows).
+static bool fused_layer(const rgcn_ctx* c) {
+  return c->fuse && c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->gemm_mode != 0 && c->d % 4 == 0 && !c->g.giant_on;
+}
+
 static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
   const float* Hin = c->H[l - 1];
@@ -424,7 +435,17 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
-  if (c->kind == RGCN_KIND_BLOCK) {
+  if (fused_layer(c)) {
+    // messages -> ONE kernel: H' = relu(dropout(H.W_self) + sum of the row's messages)
+    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    GemmEpilogue e;
+    e.mode = 1;
+    e.msg = c->msgbuf; e.row_ptr = c->g.row_ptr;
+    e.relu = l < c->L ? 1 : 0;
+    e.drop = make_drop(c, l, true);
+    e.alg_extra_bytes = 4.0 * d * Mmsg + 4.0 * V;
+    RGCN_TRY(gemm_f32(c, "layer_fwd_fused", true, false, V, d, d, Hin, d, c->layers[l].wself, d, c->H[l], d, 1, &e));
+  } else if (c->kind == RGCN_KIND_BLOCK) {
     // The relational messages (HBM-bound) run beside the self-loop GEMM.  A stream that blocks on another
     // stream's event resumes ~10 us after the event fires, so the chain that continues (the combine) stays on
     // the stream of the kernel that finishes LAST: schedule 1 keeps the messages on the main stream and
@@ -525,7 +546,27 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
   }
 
-  if (c->kind == RGCN_KIND_BLOCK) {
+  if (fused_layer(c)) {
+    // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
+    // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
+    // side streams
+    RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
+    {
+      StreamScope side(c, 0);
+      RGCN_TRY(block_dw_reduce(c, l));
+    }
+    {
+      StreamScope side(c, 1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+    }
+    GemmEpilogue e;
+    e.mode = 2;
+    e.msg = c->msgbuf; e.row_ptr = c->g.row_ptr;
+    e.gate = a.gate; e.out2 = a.out2; e.drop2 = a.drop2;
+    e.alg_extra_bytes = 4.0 * d * ((a.out2 ? 2.0 : 1.0) * V + Mmsg) + 4.0 * V;
+    RGCN_TRY(gemm_f32(c, "layer_bwd_fused", true, true, V, d, d, c->bwd_dS, d, lb.wself, d, a.out, d, 1, &e));
+  } else if (c->kind == RGCN_KIND_BLOCK) {
     {   // the relational gradient kernels (HBM-bound) run on a side stream beside the self-loop GEMMs
         // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).
       StreamScope side(c, 0);
@@ -1284,6 +1325,12 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
   RGCN_NEED(c);
   RGCN_TRY(sync_all(c));
   c->use_aux = on != 0;
+  return RGCN_OK;
+}
+
+rgcn_status rgcn_set_fusion(rgcn_ctx* c, int32_t on) {
+  RGCN_NEED(c);
+  c->fuse = on != 0;
   return RGCN_OK;
 }
 

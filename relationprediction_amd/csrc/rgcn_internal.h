@@ -72,6 +72,34 @@ struct DropSpec {
   const uint64_t* seed_offset;  // device counter added to `seed` (replayed hipGraphs draw fresh masks); may be null
 };
 
+#if defined(__HIPCC__)
+// dropout factor of flat element idx: 1/keep or 0 (1 when the spec is inactive)
+__device__ __forceinline__ float drop_factor(const DropSpec& ds, size_t idx) {
+  if (ds.mode == DROP_NONE) return 1.0f;
+  if (ds.mode == DROP_RNG)
+    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
+  return ds.mask[idx] ? ds.inv_keep : 0.0f;
+}
+#endif
+
+// What k_combine does behind the self-loop GEMM, fused into the GEMM's own epilogue (gemm_bf16x3.hip): the product
+// tile never goes to HBM and back.  Reference: MessageGcn.compute_vertex_embeddings + ConcatGcn.combine_messages
+// (message_gcn.py:60-64, gcn_basis_concat.py:69-83) forward, their tf.gradients backward.
+//   mode 1 (forward):  out = relu?( dropout(A.B) + sum over the row's message slots )
+//   mode 2 (backward): out = ( A.B + sum over the row's message slots ) * (gate > 0);  out2 = out * dropout2
+// Rows with more than kLongRow slots are summed by the whole workgroup, in k_combine's order.
+struct GemmEpilogue {
+  int32_t mode = 0;
+  const float* msg = nullptr;         // message rows [slots, d], incidence order
+  const int32_t* row_ptr = nullptr;   // [V+1]
+  const float* gate = nullptr;
+  float* out2 = nullptr;
+  int32_t relu = 0;
+  DropSpec drop;                      // mode 1: on the product
+  DropSpec drop2;                     // mode 2: on out2
+  double alg_extra_bytes = 0;         // algorithmic bytes the epilogue adds to the GEMM's own (profile accounting)
+};
+
 // ---------------------------------------------------------------- profiling records
 struct ProfRec {
   const char* name;
@@ -211,6 +239,7 @@ struct rgcn_ctx {
                                                                // 2 for the decoder's relation gradient (runs beside the backward pass)
   hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
+  bool fuse = false;                      // self-loop GEMM with the combine as its epilogue (block kind, one GPU, split arithmetic)
   std::string err;
 
   std::vector<rgcn::Param> params;
@@ -336,12 +365,12 @@ rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* 
 // `slab` ([split_k][M][N]) and reduces them into C deterministically.
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k);
+                     int split_k, const GemmEpilogue* epi = nullptr);
 
 // gemm_bf16x3.hip: the same contraction on the bf16 matrix cores (exact 3-way operand split)
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int k_per_split, int splits, int swizzle, int vecC);
+                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi = nullptr);
 
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);

@@ -562,3 +562,38 @@ def test_rccl_single_rank_communicator(native):
         buf.free()
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------ fused layer kernel == the two-kernel form
+@pytest.mark.parametrize("V,R,d,nb,E,hubs", [(300, 12, 20, 4, 2500, 3), (97, 5, 8, 2, 400, 1), (64, 3, 16, 4, 0, 0),
+                                             (2000, 30, 500, 100, 6000, 4)])
+@pytest.mark.parametrize("gen_dropout", [False, True])
+def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, hubs, gen_dropout):
+    """rgcn_set_fusion: the self-loop GEMM with the combine as its epilogue (one kernel per layer and direction) against
+    GEMM + k_combine -- same products, same summation order: every activation and every gradient BITWISE equal, with
+    hub rows (more than 32 slots: pre-reduced), injected and generated dropout, an empty graph"""
+    params, triples, masks, dcodes = make_case(V, R, d, 2, "block", nb, E, seed=V + E)
+    if hubs:
+        rng = np.random.RandomState(1)
+        for h in range(hubs):                       # a few vertices with hundreds of incident edges
+            idx = rng.choice(E, size=min(E // 8, 300), replace=False)
+            triples[idx, 2 if h % 2 == 0 else 0] = h
+    out = []
+    for fuse in (True, False):
+        eng = native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=max(E, 1))
+        try:
+            eng.set_fusion(fuse)
+            eng.set_params(params)
+            eng.set_graph(triples)
+            eng.forward(train=True, seed=11, masks=None if gen_dropout else masks)
+            acts = [eng.activation(l) for l in range(3)]
+            eng.backward(dcodes)
+            out.append((acts, eng.get_grads()))
+        finally:
+            eng.close()
+    (fa, fg), (ua, ug) = out
+    for l in range(3):
+        np.testing.assert_array_equal(fa[l], ua[l], err_msg="H%d" % l)
+    for k in fg:
+        np.testing.assert_array_equal(fg[k], ug[k], err_msg=k)
+    assert np.isfinite(fa[2]).all() and (E == 0 or np.abs(fg["W_f1"]).max() > 0)
