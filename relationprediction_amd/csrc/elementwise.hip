@@ -98,12 +98,23 @@ constexpr int kLongBlocksMin = 64;  // extra workgroups of the combine grid that
 template <int VEC, int TPR>
 __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int n_long_blocks) {
   const int nvec = a.d / VEC;
+  // [8 slot lanes][128 column lanes] partial sums of the long rows / [rows][TPR lanes] values of the ordinary rows
+  // for the fused column sums
+  __shared__ float shm[kCombineThreads * VEC];
   // the long-row workgroups come FIRST in the grid so that they start at t = 0 and finish under the
   // cover of the ordinary rows
   if ((int)blockIdx.x < n_long_blocks) {
-    __shared__ float red[8][128 * VEC];
-    if (a.msg == nullptr) return;
+    float (*red)[128 * VEC] = reinterpret_cast<float (*)[128 * VEC]>(shm);
     const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    // column sums of `out` over the rows this workgroup finishes (a.colsum_part: nvec <= 128, one column chunk)
+    float cs[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cs[k] = 0.0f;
+    if (a.msg == nullptr) {
+      if (a.colsum_part != nullptr && sl == 0 && cl < nvec)
+        vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cl * VEC, cs);
+      return;
+    }
     const int n = *a.nlong;
     for (int b = blockIdx.x; b < n; b += n_long_blocks) {
       const int v = a.long_rows[b];
@@ -156,10 +167,14 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
             tot[k] += t;
           }
           combine_epilogue<VEC>(a, off, tot);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) cs[k] += tot[k];
         }
         __syncthreads();
       }
     }
+    if (a.colsum_part != nullptr && sl == 0 && cl < nvec)
+      vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cl * VEC, cs);
     // giant rows (full-graph scale): one kGiantRow-slot PIECE per turn, partial sum to the piece slab; the
     // finishing kernel adds the pieces of a row in order and applies prologue / epilogue
     if (a.ngiant != nullptr) {
@@ -214,36 +229,59 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
   }
   const int rows_per_block = kCombineThreads / TPR;
   const int v = ((int)blockIdx.x - n_long_blocks) * rows_per_block + threadIdx.x / TPR;
-  if (v >= a.V) return;
   const int lane = threadIdx.x % TPR;
+  bool active = v < a.V;
   int beg = 0, end = 0;
-  if (a.msg != nullptr) {
+  if (active && a.msg != nullptr) {
     beg = a.row_ptr[v];
     end = a.row_ptr[v + 1];
-    if (end - beg > kLongRow) return;       // handled by a long-row workgroup of this same launch
+    if (end - beg > kLongRow) active = false;       // handled by a long-row workgroup of this same launch
   }
-  for (int cidx = lane; cidx < nvec; cidx += TPR) {
-    const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+  if (a.colsum_part == nullptr && !active) return;
+  for (int c0 = 0; c0 < nvec; c0 += TPR) {            // one turn whenever the column sums are fused (nvec <= TPR)
+    const int cidx = c0 + lane;
     float acc[VEC];
-    combine_prologue<VEC>(a, v, off, acc);
-    const float* mp = a.msg + (size_t)cidx * VEC;
-    int s = beg;
-    for (; s + 4 <= end; s += 4) {   // 4 independent 16-B loads in flight per lane
-      float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
-      vload<VEC>(mp + (size_t)(s + 0) * a.d, m0);
-      vload<VEC>(mp + (size_t)(s + 1) * a.d, m1);
-      vload<VEC>(mp + (size_t)(s + 2) * a.d, m2);
-      vload<VEC>(mp + (size_t)(s + 3) * a.d, m3);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
-    }
-    for (; s < end; ++s) {
-      float m0[VEC];
-      vload<VEC>(mp + (size_t)s * a.d, m0);
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    if (active && cidx < nvec) {
+      const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
+      combine_prologue<VEC>(a, v, off, acc);
+      const float* mp = a.msg + (size_t)cidx * VEC;
+      int s = beg;
+      for (; s + 4 <= end; s += 4) {   // 4 independent 16-B loads in flight per lane
+        float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
+        vload<VEC>(mp + (size_t)(s + 0) * a.d, m0);
+        vload<VEC>(mp + (size_t)(s + 1) * a.d, m1);
+        vload<VEC>(mp + (size_t)(s + 2) * a.d, m2);
+        vload<VEC>(mp + (size_t)(s + 3) * a.d, m3);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+        for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
+      }
+      for (; s < end; ++s) {
+        float m0[VEC];
+        vload<VEC>(mp + (size_t)s * a.d, m0);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
+      }
+      combine_epilogue<VEC>(a, off, acc);             // acc = what went to `out`
     }
-    combine_epilogue<VEC>(a, off, acc);
+    if (a.colsum_part != nullptr) {
+      // db_emb (column sums of dW_emb = `out` of the last backward combine) without another pass over [V,d]:
+      // the workgroup's rows are added in row order, one partial row per workgroup, k_colsum_final adds those
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) shm[threadIdx.x * VEC + k] = acc[k];
+      __syncthreads();
+      if (threadIdx.x < TPR && cidx < nvec) {
+        float t[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t[k] = 0.0f;
+        for (int r = 0; r < rows_per_block; ++r)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) t[k] += shm[(r * TPR + lane) * VEC + k];
+        vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cidx * VEC, t);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -420,6 +458,14 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a_in, doubl
     n_long_blocks = (int)(want < kLongBlocksMin ? kLongBlocksMin : (want > 1024 ? 1024 : want));
   }
   dim3 grid(nb_rows + n_long_blocks), block(kCombineThreads);
+  c->colsum_parts = 0;
+  if (a.colsum_part != nullptr) {
+    // fused column sums: one column chunk per row (nvec <= 128), no giant rows, room for one partial row per workgroup
+    if (vec4 && nvec <= 128 && !giant && 2 * c->g.E <= 65536 &&
+        ((size_t)grid.x + grid.x / kColRowsPerBlock + 2) * a.d <= c->colsum_part_floats)
+      c->colsum_parts = (int)grid.x;
+    else a.colsum_part = nullptr;
+  }
   ProfScope ps(c, tag, alg_bytes, 0);
 #define RGCN_LAUNCH_COMBINE(VEC, TPR) \
   hipLaunchKernelGGL((k_combine<VEC, TPR>), grid, block, 0, c->stream, a, n_long_blocks)
@@ -480,12 +526,19 @@ rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, 
 }
 
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols) {
+  float* part = c->colsum_part;
+  if (c->colsum_parts > 0) {      // the last combine left per-workgroup partial rows of exactly these sums: add THOSE
+    in = c->colsum_part;
+    rows = c->colsum_parts;
+    part = c->colsum_part + (size_t)rows * cols;      // second-level partials behind them
+    c->colsum_parts = 0;
+  }
   const int nparts = (rows + kColRowsPerBlock - 1) / kColRowsPerBlock;
   ProfScope ps(c, "bias_grad_colsum", 4.0 * rows * cols, 0);
   hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nparts), dim3(256), 0, c->stream, in,
-                     c->colsum_part, rows, cols);
+                     part, rows, cols);
   hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(1024), 0, c->stream,
-                     c->colsum_part, out, nparts, cols);
+                     part, out, nparts, cols);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

@@ -202,6 +202,23 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   }
 }
 
+// The long-row list comes out of k_ptrs in the order its atomics happened to run.  Whatever walks that list in
+// blocks (the long-row workgroups of k_combine, whose per-workgroup column sums feed db_emb) would sum in a
+// run-dependent order: put the list in ascending vertex order.  At most 65536 / 33 entries (minibatch scale): one
+// workgroup, rank by counting in LDS.
+__global__ void __launch_bounds__(1024) k_sort_long_rows(int32_t* __restrict__ long_rows, const int32_t* __restrict__ nlong) {
+  __shared__ int32_t a[2048];
+  const int n = min(*nlong, 2048);
+  for (int i = threadIdx.x; i < n; i += 1024) a[i] = long_rows[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int x = a[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += a[j] < x ? 1 : 0;      // vertices are distinct
+    long_rows[rank] = x;
+  }
+}
+
 __device__ __forceinline__ int upper_bound_dev(const int32_t* a, int n, int x) {
   // first index i in [0,n) with a[i] > x
   int lo = 0, hi = n;
@@ -480,6 +497,10 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                        g.nlong, g.long_cap,
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
                        g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr);
+  }
+  if (M > 0 && M <= 65536) {
+    ProfScope ps(c, "prep_sort_long_rows", 8.0 * (M / kLongRow), 0);
+    hipLaunchKernelGGL(k_sort_long_rows, dim3(1), dim3(1024), 0, c->stream, g.long_rows, g.nlong);
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
     ScanJobs jobs;

@@ -375,7 +375,9 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     if ((size_t)p.count > stage) stage = (size_t)p.count;
   c->stage_floats = stage;
   RGCN_TRY(dmalloc(c, &c->stage, stage, false));
-  RGCN_TRY(dmalloc(c, &c->colsum_part, ((V + 31) / 32) * d));
+  // one partial row per combine workgroup (4 rows each at worst) + the second-level partials of their sum
+  c->colsum_part_floats = ((V + 3) / 4 + 1024 + 2 + ((V + 3) / 4 + 1024) / 32 + 2) * d;
+  RGCN_TRY(dmalloc(c, &c->colsum_part, c->colsum_part_floats));
   RGCN_TRY(dmalloc(c, &c->zeros, 64));
   RGCN_TRY(graph_alloc(c, nullptr));
   std::swap(c->g, c->g_alt);
@@ -539,6 +541,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
     a.out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
+    if (l - 1 == 0) a.colsum_part = c->colsum_part;      // db_emb = column sums of dW_emb, gathered on the way
     a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
     a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
     a.gate = Hin;
