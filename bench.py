@@ -417,8 +417,11 @@ def measure(workload, args, rk, steps, warmup, full):
                                 + ("; replayed from a captured hipGraph (2 steps per launch)" if use_graph else ""))
                                if pipeline else
                                "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
-                       "parallelism": "relation-sharded x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": "relation-sharded x%d + RCCL reduce-scatter / all-gather per layer, one all-reduce "
+                                      "of the replicated weight gradients" % world if world > 1 else "single GPU"},
             "gpu_event_ms_per_step": round(gpu_ms / steps, 4),
+            # collectives of one step on this rank (exclusive durations of the rccl_* launches; N = 1: none)
+            "comm_ms_per_step": round(sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("rccl_")), 4),
             "message_edges_per_s": round(2 * L * value, 1),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,

@@ -1,5 +1,8 @@
 // RCCL binding for the relation-sharded path (new: the reference is single-device).
-// One [V,d] fp32 sum-all-reduce per layer per direction over xGMI.  librccl.so.1 is dlopen'ed on
+// Per layer and direction the partial [V,d] sums are REDUCE-SCATTERED over the row shards (every rank finishes its own
+// rows: relu / relu' / dropout on V/N rows instead of V), then the finished rows are ALL-GATHERED on a side stream
+// while the next self-loop GEMM -- which needs only the rank's own rows -- already runs; the replicated weight
+// gradients of all layers travel in ONE all-reduce at the end of the backward pass.  librccl.so.1 is dlopen'ed on
 // first use so that a single-GPU context never depends on it; if another RCCL client in the
 // process (e.g. torch) already mapped a librccl.so.1, the loader hands back that same image.
 #include <dlfcn.h>
@@ -23,6 +26,8 @@ struct Rccl {
   int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
   int (*CommDestroy)(nccl_comm_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
 };
@@ -57,8 +62,11 @@ bool load_rccl(std::string* err) {
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+  r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(r.handle, "ncclReduceScatter");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.ReduceScatter || !r.AllGather ||
+      !r.GetErrorString) {
     *err = "librccl.so.1 lacks an expected nccl* symbol";
     dlclose(r.handle);
     r.handle = nullptr;
@@ -106,6 +114,29 @@ rgcn_status comm_allreduce(rgcn_ctx* c, float* buf, int64_t count) {
   ProfScope ps(c, "rccl_allreduce", 8.0 * count, 0);
   int rc = rccl().AllReduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, (nccl_comm_t)c->comm, c->stream);
   if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclAllReduce", rc));
+  return RGCN_OK;
+}
+
+// In place over a buffer of world * count floats: this rank's chunk [rank*count, +count) receives the sum of every
+// rank's chunk.
+rgcn_status comm_reduce_scatter(rgcn_ctx* c, float* buf, int64_t count) {
+  if (!c->comm) RGCN_FAIL(c, RGCN_ERR_STATE, "no communicator: call rgcn_comm_init first");
+  if (count <= 0) return RGCN_OK;
+  ProfScope ps(c, "rccl_reduce_scatter", 4.0 * count * (c->world + 1), 0);
+  int rc = rccl().ReduceScatter(buf, buf + (size_t)c->rank * count, (size_t)count, kNcclFloat32, kNcclSum,
+                                (nccl_comm_t)c->comm, c->stream);
+  if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclReduceScatter", rc));
+  return RGCN_OK;
+}
+
+// In place over a buffer of world * count floats: every rank contributes its chunk [rank*count, +count).
+rgcn_status comm_all_gather(rgcn_ctx* c, float* buf, int64_t count) {
+  if (!c->comm) RGCN_FAIL(c, RGCN_ERR_STATE, "no communicator: call rgcn_comm_init first");
+  if (count <= 0) return RGCN_OK;
+  ProfScope ps(c, "rccl_all_gather", 4.0 * count * (c->world + 1), 0);
+  int rc = rccl().AllGather(buf + (size_t)c->rank * count, buf, (size_t)count, kNcclFloat32, (nccl_comm_t)c->comm,
+                            c->stream);
+  if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclAllGather", rc));
   return RGCN_OK;
 }
 

@@ -228,9 +228,10 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
     return;
   }
   const int rows_per_block = kCombineThreads / TPR;
-  const int v = ((int)blockIdx.x - n_long_blocks) * rows_per_block + threadIdx.x / TPR;
+  const int local = ((int)blockIdx.x - n_long_blocks) * rows_per_block + threadIdx.x / TPR;
+  const int v = a.v_begin + local;
   const int lane = threadIdx.x % TPR;
-  bool active = v < a.V;
+  bool active = local < (a.v_count < 0 ? a.V : a.v_count) && v < a.V;
   int beg = 0, end = 0;
   if (active && a.msg != nullptr) {
     beg = a.row_ptr[v];
@@ -450,7 +451,8 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a_in, doubl
   const int nvec = vec4 ? a.d / 4 : a.d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
   const int rows_per_block = kCombineThreads / tpr;
-  const int nb_rows = (a.V + rows_per_block - 1) / rows_per_block;
+  const int nrows = a.v_count < 0 ? a.V : a.v_count;
+  const int nb_rows = (nrows + rows_per_block - 1) / rows_per_block;
   // enough long-row workgroups for the graph at hand: one per ~1024 slots, at least 64, at most 1024
   int n_long_blocks = 0;
   if (a.msg != nullptr) {

@@ -195,6 +195,10 @@ static void free_all(rgcn_ctx* c) {
   if (c->giant_slab) (void)hipFree(c->giant_slab);
   F(c->w_emb); F(c->g_emb); F(c->b_emb); F(c->gb_emb); F(c->w_rel); F(c->g_rel);
   for (LayerBufs& lb : c->layers) {
+    if (c->repl_grads) {      // views into repl_grads
+      lb.gwself = nullptr;
+      if (c->kind == RGCN_KIND_BASIS) lb.grel = nullptr;
+    }
     F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);
   }
   for (float* h : c->H) F(h);
@@ -210,6 +214,8 @@ static void free_all(rgcn_ctx* c) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
+  F(c->repl_grads);
   if (c->ev_step_begin) (void)hipEventDestroy(c->ev_step_begin);
   for (hipGraphExec_t g : c->graphs) if (g) (void)hipGraphExecDestroy(g);
   for (hipGraph_t g : c->graph_defs) if (g) (void)hipGraphDestroy(g);
@@ -257,8 +263,11 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     c->B = f.num_bases;
     if (c->B > 64) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "NumberOfBasisFunctions > 64 (basis)");
   }
-  c->row_lo = (int)((int64_t)c->rank * c->V / c->world);
-  c->row_hi = (int)((int64_t)(c->rank + 1) * c->V / c->world);
+  // equal row chunks (the reduce-scatter / all-gather want them equal): rank g finishes rows [g * shard_rows, +shard_rows)
+  c->shard_rows = (c->V + c->world - 1) / c->world;
+  c->V_pad = c->shard_rows * c->world;
+  c->row_lo = std::min(c->V, c->rank * c->shard_rows);
+  c->row_hi = std::min(c->V, c->row_lo + c->shard_rows);
 
   RGCN_HIP(c, hipSetDevice(f.device));
   RGCN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -300,7 +309,10 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_HIP(c, hipEventCreate(&c->t0));
   RGCN_HIP(c, hipEventCreate(&c->t1));
 
-  const size_t V = c->V, d = c->d, R = c->R, Vd = V * d;
+  // every [V,d] buffer carries V_pad rows (== V on one GPU): the collectives work on world equal chunks, the
+  // padding rows stay zero
+  const size_t V = c->V, d = c->d, R = c->R, Vd = (size_t)c->V_pad * d;
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
   RGCN_TRY(dmalloc(c, &c->w_emb, Vd));
   RGCN_TRY(dmalloc(c, &c->g_emb, Vd));
   RGCN_TRY(dmalloc(c, &c->b_emb, d));
@@ -308,9 +320,17 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   add_param(c, "W_emb", {(int64_t)V, (int64_t)d}, c->w_emb, c->g_emb, LAYOUT_PLAIN);
   add_param(c, "b_emb", {(int64_t)d}, c->b_emb, c->gb_emb, LAYOUT_PLAIN);
   c->layers.resize(c->L + 1);
+  // world > 1: the gradients every rank holds a partial sum of -- W_self, and the basis tensors -- sit in ONE
+  // allocation, layer after layer, so that the backward pass ends with one all-reduce instead of 2-3 per layer
+  const size_t repl_per_layer = d * d + (c->kind == RGCN_KIND_BASIS ? 2 * (size_t)f.num_bases * d * d : 0);
+  if (c->world > 1) {
+    c->repl_grads_floats = repl_per_layer * c->L;
+    RGCN_TRY(dmalloc(c, &c->repl_grads, c->repl_grads_floats));
+  }
   for (int l = 1; l <= c->L; ++l) {
     LayerBufs& lb = c->layers[l];
     const std::string sl = std::to_string(l);
+    float* repl = c->repl_grads ? c->repl_grads + repl_per_layer * (l - 1) : nullptr;
     if (c->kind == RGCN_KIND_BLOCK) {
       const size_t per_dir = R * c->nb * c->sd * c->sd;
       RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));
@@ -320,7 +340,8 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     } else {
       const size_t per_dir = (size_t)c->B * d * d;
       RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));
-      RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
+      if (repl) lb.grel = repl + d * d;
+      else RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
       RGCN_TRY(dmalloc(c, &lb.coef, 2 * R * c->B));
       RGCN_TRY(dmalloc(c, &lb.gcoef, 2 * R * c->B));
       add_param(c, "W_f" + sl, {(int64_t)d, c->B, (int64_t)d}, lb.wrel, lb.grel, LAYOUT_BASIS_T);
@@ -329,7 +350,8 @@ static rgcn_status create_impl(rgcn_ctx* c) {
       add_param(c, "C_b" + sl, {(int64_t)R, c->B}, lb.coef + R * c->B, lb.gcoef + R * c->B, LAYOUT_PLAIN);
     }
     RGCN_TRY(dmalloc(c, &lb.wself, d * d));
-    RGCN_TRY(dmalloc(c, &lb.gwself, d * d));
+    if (repl) lb.gwself = repl;
+    else RGCN_TRY(dmalloc(c, &lb.gwself, d * d));
     RGCN_TRY(dmalloc(c, &lb.bias, d));
     RGCN_TRY(dmalloc(c, &lb.gbias, d));
     add_param(c, "W_self" + sl, {(int64_t)d, (int64_t)d}, lb.wself, lb.gwself, LAYOUT_PLAIN);
@@ -424,6 +446,26 @@ static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_
   return input_forward(c);
 }
 
+// The all-gather of the rows finished last runs on side stream 1; whoever needs ALL rows (message kernels, the
+// decoder, the column sums) makes its stream wait here, whoever needs the rank's own rows only (self-loop GEMMs) does not.
+static rgcn_status wait_gather(rgcn_ctx* c) {
+  if (c->gather_pending) {
+    RGCN_HIP(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));
+    if (c->stream == c->main_stream) c->gather_pending = false;
+  }
+  return RGCN_OK;
+}
+// all-gather the [V_pad,d] buffer whose own rows this rank just finished, beside whatever the main stream does next
+static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
+  StreamScope side(c, 1);
+  RGCN_TRY(comm_all_gather(c, buf, (int64_t)c->shard_rows * c->d));
+  if (side.active) {
+    RGCN_HIP(c, hipEventRecord(c->ev_gather, c->aux[1]));
+    c->gather_pending = true;
+  }
+  return RGCN_OK;
+}
+
 // The self-loop GEMM takes the combine as its epilogue: block kind, one GPU, split arithmetic (the fp32-MFMA kernel
 // keeps the two-kernel form), 16-byte rows, minibatch scale (no giant rows).
 static bool fused_layer(const rgcn_ctx* c) {
@@ -459,10 +501,12 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
         RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
                           c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
       }
+      RGCN_TRY(wait_gather(c));
       RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
     } else {
       {
         StreamScope side(c, 0);
+        RGCN_TRY(wait_gather(c));
         RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
@@ -481,6 +525,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   } else {
     // aggregate first: Z[v,(dir,b),:] = sum n C[rel,b] H[src];  pre = dropout(H.W_self) + Z.W'
     const int zc = 2 * c->B * d;
+    RGCN_TRY(wait_gather(c));
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
     RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
                       c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
@@ -573,6 +618,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     {   // the relational gradient kernels (HBM-bound) run on a side stream beside the self-loop GEMMs
         // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).
       StreamScope side(c, 0);
+      RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
       // the combine below needs only the message rows: mark the join point here, then let the
       // per-relation dW reduction trail behind on the side stream
@@ -609,6 +655,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                       c->self_buf + (size_t)lo * d, d, 1));
     // dZ = D . W'^T   ([V,d] x [d,2B.d]);   dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
+    RGCN_TRY(wait_gather(c));            // D_l of every row
     RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, zc, d, c->bwd_D, d, lb.wrel, d, c->msgbuf2, zc, 1));
     RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
                       auto_split_k(zc, d, V)));
@@ -648,14 +695,52 @@ static rgcn_status bwd_end(rgcn_ctx* c) {
   return stream_join(c, 0);   // trailing per-relation dW reductions
 }
 
+// Sharded run with a communicator, forward exchange of layer l: the partial pre-activations are reduce-scattered,
+// this rank applies the relu to ITS rows only, and the finished rows are all-gathered on side stream 1 while the main
+// stream goes on (the next self-loop GEMM needs the rank's own rows, nothing else).
+static rgcn_status fwd_exchange(rgcn_ctx* c, int l) {
+  const int64_t chunk = (int64_t)c->shard_rows * c->d;
+  RGCN_TRY(comm_reduce_scatter(c, c->exch, chunk));
+  const size_t off = (size_t)c->rank * chunk;
+  RGCN_TRY(relu_copy(c, c->exch + off, c->H[l] + off, chunk, l < c->L ? 1 : 0));
+  RGCN_TRY(gather_rows(c, c->H[l]));
+  if (l == c->L) {
+    RGCN_TRY(wait_gather(c));          // the codes: every row, on the main stream
+    c->fwd_done = true;
+  }
+  return RGCN_OK;
+}
+
+// Backward exchange of layer l: partial dH reduce-scattered, (relu', dropout) on the rank's rows, D_{l-1} gathered.
+static rgcn_status bwd_exchange(rgcn_ctx* c, int l) {
+  const int64_t chunk = (int64_t)c->shard_rows * c->d;
+  RGCN_TRY(comm_reduce_scatter(c, c->exch, chunk));
+  float* out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
+  DropSpec d2 = make_drop(c, l - 1, l - 1 >= 1);
+  float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
+  CombineArgs a;
+  a.add = nullptr;
+  a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
+  a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = c->row_lo; a.row_hi = c->row_hi;
+  a.v_begin = c->row_lo; a.v_count = c->row_hi - c->row_lo;
+  a.drop = make_drop(c, l, false);
+  a.drop2 = d2;
+  if (a.v_count > 0) RGCN_TRY(combine(c, "combine_bwd_finish", a, 4.0 * c->d * (out2 ? 4.0 : 3.0) * a.v_count));
+  RGCN_TRY(gather_rows(c, out));
+  c->bwd_D = out;
+  c->bwd_dS = out2 ? out2 : out;      // own rows only: all the row-sharded self-loop GEMMs read
+  c->bwd_layer = l - 1;
+  return RGCN_OK;
+}
+
 static rgcn_status forward_all(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks) {
   if (c->world > 1 && !c->comm)
     RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
   RGCN_TRY(fwd_begin(c, train, seed, masks));
   for (int l = 1; l <= c->L; ++l) {
     RGCN_TRY(fwd_layer_partial(c, l));
-    if (c->world > 1) RGCN_TRY(comm_allreduce(c, c->exch, (int64_t)c->V * c->d));
-    RGCN_TRY(fwd_layer_finish(c, l));
+    if (c->world > 1) RGCN_TRY(fwd_exchange(c, l));
+    else RGCN_TRY(fwd_layer_finish(c, l));
   }
   return RGCN_OK;
 }
@@ -666,13 +751,13 @@ static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev) {
   RGCN_TRY(bwd_begin(c, dcodes_dev));
   for (int l = c->L; l >= 1; --l) {
     RGCN_TRY(bwd_layer_partial(c, l));
-    if (c->world > 1) {
-      RGCN_TRY(comm_allreduce(c, c->exch, (int64_t)c->V * c->d));
-      RGCN_TRY(comm_allreduce(c, c->layers[l].gwself, (int64_t)c->d * c->d));
-      if (c->kind == RGCN_KIND_BASIS)   // the basis tensors are replicated: their gradient is a sum over shards
-        RGCN_TRY(comm_allreduce(c, c->layers[l].grel, (int64_t)2 * c->B * c->d * c->d));
-    }
-    RGCN_TRY(bwd_layer_finish(c, l));
+    if (c->world > 1) RGCN_TRY(bwd_exchange(c, l));
+    else RGCN_TRY(bwd_layer_finish(c, l));
+  }
+  if (c->world > 1) {
+    RGCN_TRY(wait_gather(c));          // dW_emb of every row (optimizer, column sums)
+    // W_self (and basis W') gradients of all layers: partial sums over the row / relation shards, one collective
+    RGCN_TRY(comm_allreduce(c, c->repl_grads, (int64_t)c->repl_grads_floats));
   }
   return bwd_end(c);
 }

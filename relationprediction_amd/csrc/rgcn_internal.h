@@ -232,7 +232,13 @@ struct rgcn_ctx {
   rgcn_config cfg;
   int V = 0, R = 0, d = 0, L = 0, nb = 0, sd = 0, kind = 0, B = 0;
   int rank = 0, world = 1;
-  int row_lo = 0, row_hi = 0;   // self-loop row shard of this rank
+  int row_lo = 0, row_hi = 0;   // row shard of this rank: [rank * shard_rows, +shard_rows) cut at V
+  int shard_rows = 0;           // ceil(V / world): equal chunks for the reduce-scatter / all-gather
+  int V_pad = 0;                // world * shard_rows: rows every exchanged [V,d] buffer is allocated with
+  float* repl_grads = nullptr;  // world > 1: W_self (and basis W') gradients of all layers, contiguous -> ONE all-reduce
+  size_t repl_grads_floats = 0;
+  hipEvent_t ev_gather = nullptr;   // the all-gather of the rows finished last (side stream 1) is complete
+  bool gather_pending = false;      // ... and somebody still has to wait for it
   hipStream_t stream = nullptr;           // stream launches go to (main stream unless a StreamScope is active)
   hipStream_t main_stream = nullptr;
   hipStream_t aux[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};  // side streams: 0, 1 for independent kernels of one layer,
@@ -413,6 +419,7 @@ struct CombineArgs {
   int32_t V, d;
   int32_t relu;
   int32_t row_lo, row_hi;
+  int32_t v_begin = 0, v_count = -1;   // rows the launch walks: [v_begin, v_begin + v_count) (v_count < 0: all V)
   DropSpec drop;         // applied to base
   DropSpec drop2;        // applied to out2
   float* colsum_part = nullptr;   // optional: per-workgroup column sums of `out` (one row of d floats per workgroup)
@@ -447,6 +454,8 @@ void optimizer_free(rgcn_ctx* c);
 rgcn_status comm_unique_id(uint8_t id[128]);
 rgcn_status comm_init(rgcn_ctx* c, const uint8_t id[128]);
 rgcn_status comm_allreduce(rgcn_ctx* c, float* buf, int64_t count);
+rgcn_status comm_reduce_scatter(rgcn_ctx* c, float* buf, int64_t count_per_rank);
+rgcn_status comm_all_gather(rgcn_ctx* c, float* buf, int64_t count_per_rank);
 void comm_destroy(rgcn_ctx* c);
 
 }  // namespace rgcn

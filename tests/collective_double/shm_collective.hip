@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE, not product code: a stand-in for librccl.so that lets several ranks run as separate
-// PROCESSES ON ONE GPU (RCCL itself refuses two ranks on one device).  It implements the five nccl* entry points
+// PROCESSES ON ONE GPU (RCCL itself refuses two ranks on one device).  It implements the nccl* entry points
 // csrc/comm.hip binds, with the all-reduce staged through a file-backed shared mapping: every rank copies its
 // buffer to its slot, all ranks add the slots in rank order (so every rank computes the same bits), and copy the
 // sum back.  Selected with RGCN_RCCL_LIBRARY=<this .so>; used by tests/test_gpu_multiprocess.py to drive the
@@ -115,6 +115,46 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
   hipError_t e = hipMemcpyAsync(recv, out, count * 4, hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   free(out);
+  return e == hipSuccess ? 0 : 1;
+}
+
+// recv (count floats) = sum over ranks of their send[rank * count, +count)
+int ncclReduceScatter(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (dtype != 7 || op != 0) return 4;
+  const size_t total = count * (size_t)c->nranks;
+  if (total * 4 > kSlotBytes) return 4;
+  if (hipMemcpyAsync(c->slot(c->rank), send, total * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+  if (!barrier(c)) return 3;
+  float* out = static_cast<float*>(malloc(count * 4));
+  if (!out) return 2;
+  const size_t off = (size_t)c->rank * count;
+  memcpy(out, c->slot(0) + off, count * 4);
+  for (int r = 1; r < c->nranks; ++r) {
+    const float* s = c->slot(r) + off;
+    for (size_t i = 0; i < count; ++i) out[i] += s[i];
+  }
+  if (!barrier(c)) { free(out); return 3; }
+  hipError_t e = hipMemcpyAsync(recv, out, count * 4, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  free(out);
+  return e == hipSuccess ? 0 : 1;
+}
+
+// recv (nranks * count floats) = the ranks' send buffers (count floats each) in rank order
+int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (dtype != 7) return 4;
+  if (count * 4 > kSlotBytes) return 4;
+  if (hipMemcpyAsync(c->slot(c->rank), send, count * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+  if (!barrier(c)) return 3;
+  hipError_t e = hipSuccess;
+  for (int r = 0; r < c->nranks && e == hipSuccess; ++r)
+    e = hipMemcpyAsync(static_cast<float*>(recv) + (size_t)r * count, c->slot(r), count * 4, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (!barrier(c)) return 3;
   return e == hipSuccess ? 0 : 1;
 }
 

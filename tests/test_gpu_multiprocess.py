@@ -1,7 +1,8 @@
 """The multi-process paths on the one-GPU test box: several ranks as separate processes on ONE device, with the
 shared-memory stand-in of tests/collective_double bound in place of librccl (RGCN_RCCL_LIBRARY; RCCL itself
 refuses two ranks on one GPU).  Covers what the in-process phase-API tests cannot: the library's own
-comm_allreduce call sites (rgcn_step_device / rgcn_train_step_device on world > 1 contexts) and bench.py's whole
+exchange call sites -- reduce-scatter of the partial rows, all-gather of the finished ones on a side stream, one
+all-reduce of the replicated weight gradients -- (rgcn_step_device / rgcn_train_step_device on world > 1 contexts) and bench.py's whole
 --gpus N control flow under the torch.distributed.run launcher."""
 import json
 import os
@@ -31,7 +32,8 @@ def launch(nproc, port, script_args, collective, extra_env=None, timeout=240):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("world,kind,nb", [(2, "block", 8), (3, "block", 8), (2, "basis", 2)])
+@pytest.mark.parametrize("world,kind,nb", [(2, "block", 8), (3, "block", 8), (4, "block", 8), (2, "basis", 2),
+                                           (3, "basis", 2)])
 def test_sharded_steps_across_processes(collective, world, kind, nb):
     r = launch(world, 29600 + world + (10 if kind == "basis" else 0),
                [os.path.join(DOUBLE, "sharded_worker.py"), kind, str(nb)], collective)
@@ -49,4 +51,6 @@ def test_bench_multi_rank_prints_one_json_line_last(collective, world):
     assert sum(1 for l in lines if l.startswith("{")) == 1
     assert out["n_gpus"] == world and out["steps"] == 4 and out["value"] > 0
     assert out["config"]["parallelism"].startswith("relation-sharded x%d" % world)
-    assert out["roofline"] and any(k["kernel"] == "rccl_allreduce" for k in out["kernels"])
+    names = {k["kernel"] for k in out["kernels"]}
+    assert out["roofline"] and {"rccl_allreduce", "rccl_reduce_scatter", "rccl_all_gather"} <= names
+    assert out["comm_ms_per_step"] > 0
