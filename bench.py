@@ -110,6 +110,8 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra workload")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-fp32-reference", action="store_true",
+                    help="skip the extra timed run with the dense contractions on the fp32 MFMA (rocprofv3 passes)")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay the steps from a captured hipGraph (two steps + their prefetches per launch; "
                          "single GPU only)")
@@ -145,9 +147,7 @@ def traffic_table(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*traffic*.json,
     FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be collected from inside the process"""
     try:
-        named = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_%s.json" % workload)))
-        plain = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_serial_traffic.json"))) if workload == "fb237_block" else []
-        pick = (named or plain)
+        pick = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_%s_serial_traffic.json" % workload)))
         if pick:
             return json.load(open(pick[-1]))["kernels"], os.path.relpath(pick[-1], ROOT)
     except Exception:  # noqa: BLE001
@@ -263,7 +263,7 @@ def measure(workload, args, rk, steps, warmup, full):
 
     # ---- the same step with the dense contractions on the fp32 MFMA (mode 0), for reference
     fp32_ref = None
-    if full and args.gemm_mode != 0:
+    if full and args.gemm_mode != 0 and not args.no_fp32_reference:
         n2 = max(10, steps // 2)
         eng.set_gemm_mode(0)
         run(3, 3000)

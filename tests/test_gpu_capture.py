@@ -148,3 +148,16 @@ def test_config5_fb15k_train_step_in_a_hipgraph(native):
                 b.free()
         for e in engines:
             e.close()
+
+
+def test_capture_on_a_sharded_context_is_refused_by_default(native):
+    """BASELINE config 5 asks for a captured train step on 8 GPUs; the collectives inside such a step cannot be
+    exercised on the one-GPU box (the test collective synchronises on the host), so the library refuses unless
+    RGCN_CAPTURE_SHARDED=1 -- loudly, with RGCN_ERR_UNSUPPORTED, instead of capturing something it never ran"""
+    eng = native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2)
+    try:
+        with pytest.raises(native.RgcnError) as err:
+            eng.capture_begin()
+        assert "RGCN_CAPTURE_SHARDED" in str(err.value)
+    finally:
+        eng.close()

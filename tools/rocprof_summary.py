@@ -47,6 +47,7 @@ def counter_avg(db, counter):
 
 def main():
     d, outp = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-kernel-profile"
     ks = kernel_stats(d + "/trace/trace_results.db")
     try:
         fetch = counter_avg(d + "/pmc_fetch/fetch_results.db", "FETCH_SIZE")
@@ -56,7 +57,7 @@ def main():
         fetch, write = {}, {}
     total = sum(v[1] for v in ks.values())
     lines = ["# rocprofv3 summary (%s)" % d, "",
-             "command: `python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-kernel-profile` "
+             "command: `%s` " % cmd +
              "(25 steps incl. warm-up); kernel-trace pass for durations, separate `--pmc FETCH_SIZE` / "
              "`--pmc WRITE_SIZE` passes for bytes.", "",
              "HBM MB/launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 1e6 (gfx950 FETCH_SIZE half-count "
