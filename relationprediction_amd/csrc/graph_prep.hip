@@ -89,8 +89,11 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
 __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
                        const int32_t* __restrict__ owner, int rank, uint32_t* keyv,
                        uint32_t* keyr, int count_degrees, int32_t* indeg, int32_t* outdeg,
-                       int32_t* errflag) {
+                       int32_t* errflag, int32_t* small_counters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // one GPU: the degrees are overwritten row by row (k_ptrs reads them off the sorted rows), only the long / giant row
+  // counters need a zero before k_ptrs counts into them -- no memset launch
+  if (small_counters != nullptr && i < 3) small_counters[i] = 0;
   if (i >= 2 * E) return;
   const bool fwd = i < E;
   const int e = fwd ? i : i - E;
@@ -476,13 +479,15 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   g.ready = false;
   g.pf_valid = false;
   c->fwd_done = false;
-  RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
+  const bool zero_in_keys = c->world == 1 && E > 0;      // (sharded: the degree counters are atomically added to)
+  if (!zero_in_keys) RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
   const int T = 256;
   if (E > 0) {
     {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
-                         c->rank, g.keyv, g.keyr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg, g.errflag);
+                         c->rank, g.keyv, g.keyr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg, g.errflag,
+                         zero_in_keys ? g.nlong : (int32_t*)nullptr);
     }
     // incidences by vertex (-> permv, pos) and messages by directed relation (-> permr), in the same launches
     SortSpec sp[2];
