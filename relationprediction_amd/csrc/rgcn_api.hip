@@ -616,7 +616,9 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(gemm_f32(c, "layer_bwd_fused", true, true, V, d, d, c->bwd_dS, d, lb.wself, d, a.out, d, 1, &e));
   } else if (c->kind == RGCN_KIND_BLOCK) {
     {   // the relational gradient kernels (HBM-bound) run on a side stream beside the self-loop GEMMs
-        // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).
+        // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).  (Tried: the message
+        // kernel on the main stream and both GEMMs on side streams, so that the main stream never waits across
+        // streams -- 0.655 ms per step against 0.62.)
       StreamScope side(c, 0);
       RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
