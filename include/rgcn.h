@@ -74,7 +74,9 @@ enum {
    * incidence i < E = edge i seen from its object, i >= E = edge i-E seen from its subject; message m likewise with
    * directed relation r (m < E) or R + r */
   RGCN_BUF_PERM_VERTEX = 8,     /* int32 [2E] incidence ids in incidence-CSR order (by vertex, ties by id) */
-  RGCN_BUF_PERM_RELATION = 9    /* int32 [2E] message ids in message-list order (by directed relation, ties by id) */
+  RGCN_BUF_PERM_RELATION = 9,   /* int32 [2E] message ids in message-list order (by directed relation, ties by id) */
+  RGCN_BUF_RANK_ENERGIES = 10   /* float [reserved queries, V] energies of the last chunk rgcn_rank_device scored (the
+                                   float half of the ranking; the counts are integer work on exactly these values) */
 };
 
 /*

@@ -23,7 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 
 __all__ = [
-    "KIND_BLOCK", "KIND_BASIS", "NORM_INTENDED", "NORM_TF_AS_EXECUTED", "NORM_NONE", "distmult_ranks", "sample_edge_neighborhood",
+    "KIND_BLOCK", "KIND_BASIS", "NORM_INTENDED", "NORM_TF_AS_EXECUTED", "NORM_NONE", "distmult_ranks", "ranks_from_energies", "sample_edge_neighborhood",
     "glorot_variance", "init_params", "weight_names", "split_graph",
     "incidence_values", "incidence_matrix", "affine_onehot_forward",
     "concat_messages", "basis_messages", "self_loop", "dropout", "combine_messages",
@@ -398,13 +398,23 @@ def distmult_loss_and_grads(codes, W_relation, X, Y, reg_param=0.01):
 
 # --------------------------------------------------------------------------- workload builders
 
+def ranks_from_energies(energies, gold, known_idx):
+    """MrrScore.append_line (evaluation.py:148-153) on one row of energies: the integer half of the ranking.
+    raw = #{score >= score[gold]}, filtered = raw - #{known with score >= score[gold]} + 1, on fp32 sigmoid values
+    (bilinear_diag.py:51-61; sigmoid in float64, rounded once to float32: saturated scores tie, as in TF)."""
+    with np.errstate(over="ignore"):
+        scores = (1.0 / (1.0 + np.exp(-np.asarray(energies, dtype=np.float64)))).astype(np.float32)
+    g = scores[gold]
+    n_raw = int(np.sum(scores >= g))
+    idx = np.asarray(known_idx, dtype=np.int64)
+    return n_raw, n_raw - int(np.sum(scores[idx] >= g)) + 1
+
+
 def distmult_ranks(codes, W_relation, triples, predict_object, known):
     """Raw and filtered ranks as the reference computes them: scores against every entity
-    (bilinear_diag.py:51-61: sigmoid of the energies), then MrrScore.append_line (evaluation.py:148-153):
-    raw = #{score >= score[gold]}, filtered = raw - #{known with score >= score[gold]} + 1.
+    (bilinear_diag.py:51-61: sigmoid of the energies), then ranks_from_energies.
     ``known`` maps (entity, relation) -> list of completing entities (Scorer.known_object_triples for
-    predict_object, known_subject_triples otherwise; evaluation.py:232-270).  The sigmoid is evaluated in
-    float64 and rounded once to float32, then compared in float32 (saturated scores tie, as in TF)."""
+    predict_object, known_subject_triples otherwise; evaluation.py:232-270)."""
     codes = np.asarray(codes, dtype=F32)
     rel = np.asarray(W_relation, dtype=F32)
     raw, filt = [], []
@@ -413,14 +423,9 @@ def distmult_ranks(codes, W_relation, triples, predict_object, known):
             q, gold, key = codes[s] * rel[r], o, (s, r)
         else:
             q, gold, key = rel[r] * codes[o], s, (o, r)
-        energies = (codes @ q).astype(F32)
-        with np.errstate(over="ignore"):
-            scores = (1.0 / (1.0 + np.exp(-energies.astype(np.float64)))).astype(F32)
-        g = scores[gold]
-        n_raw = int(np.sum(scores >= g))
-        idx = np.asarray(known[key], dtype=np.int64)
-        raw.append(n_raw)
-        filt.append(n_raw - int(np.sum(scores[idx] >= g)) + 1)
+        a, b = ranks_from_energies((codes @ q).astype(F32), gold, known[key])
+        raw.append(a)
+        filt.append(b)
     return np.asarray(raw, dtype=np.int32), np.asarray(filt, dtype=np.int32)
 
 

@@ -19,7 +19,7 @@ ABI_VERSION = 1
 KIND_BLOCK, KIND_BASIS = 0, 1
 NORM_INTENDED, NORM_TF_AS_EXECUTED, NORM_NONE = 0, 1, 2
 BUF_EXCHANGE, BUF_SELF, BUF_DSELF_EXCHANGE, BUF_INDEG, BUF_OUTDEG, BUF_ROWPTR, BUF_NORM_EXCHANGE, \
-    BUF_DBASIS_EXCHANGE, BUF_PERM_VERTEX, BUF_PERM_RELATION = range(10)
+    BUF_DBASIS_EXCHANGE, BUF_PERM_VERTEX, BUF_PERM_RELATION, BUF_RANK_ENERGIES = range(11)
 
 KINDS = {"block": KIND_BLOCK, "basis": KIND_BASIS}
 NORMS = {"intended": NORM_INTENDED, "tf_as_executed": NORM_TF_AS_EXECUTED, "none": NORM_NONE}
@@ -463,6 +463,7 @@ class Engine:
 
     def rank_reserve(self, max_queries):
         self._check(self.lib.rgcn_rank_reserve(self.ctx, int(max_queries)))
+        self._rank_reserved = max(getattr(self, "_rank_reserved", 0), int(max_queries))
 
     def ranks(self, triples, predict_object, filter_ptr, filter_idx):
         """Raw and filtered ranks (include/rgcn.h rgcn_rank_device) of the gold subject / object of every
@@ -535,6 +536,8 @@ class Engine:
             out = np.empty(self.V + 1, dtype=np.int32)
         elif which in (BUF_PERM_VERTEX, BUF_PERM_RELATION):
             out = np.empty(2 * self.num_edges, dtype=np.int32)
+        elif which == BUF_RANK_ENERGIES:
+            out = np.empty((getattr(self, "_rank_reserved", 0), self.V), dtype=np.float32)
         elif which == BUF_DSELF_EXCHANGE:
             out = np.empty((self.d, self.d), dtype=np.float32)
         elif which == BUF_NORM_EXCHANGE:

@@ -367,8 +367,15 @@ __global__ void k_basis_dcoef_reduce(const float* __restrict__ slab, const int32
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R2 * B) return;
   const int rel = i / B, b = i - rel * B;
-  float acc = 0.f;
-  for (int c = chunk_ptr[rel]; c < chunk_ptr[rel + 1]; ++c) acc += slab[(size_t)c * B + b];
+  // a popular relation is cut into hundreds of chunks whose partial sums cancel: compensated (Kahan) summation in
+  // chunk order keeps the coefficient gradient at the fp32 oracle's distance from float64 (test_float64_tie_break)
+  float acc = 0.f, comp = 0.f;
+  for (int c = chunk_ptr[rel]; c < chunk_ptr[rel + 1]; ++c) {
+    const float y = slab[(size_t)c * B + b] - comp;
+    const float t = acc + y;
+    comp = (t - acc) - y;
+    acc = t;
+  }
   gcoef[i] = acc;
 }
 

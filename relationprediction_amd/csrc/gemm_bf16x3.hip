@@ -86,9 +86,13 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // remainder below 2^-26 |x| that is zero unless all three roundings went the same way).
 // (v_dot2c_f32_bf16 against the pairs (-1, -0), (-0, -1) computes the same residuals in one instruction,
 // but it holds up the matrix pipe for ~10 cycles where a plain VALU op costs 2: tools/mfma_fill.hip.)
+// negmask (0 or 0x80000000, first level of the A operand only) splits -x instead of x: see the accumulator sign groups
+// in the kernel.
 template <int I0, int I1>
-__device__ __forceinline__ uint32_t split_level(f32x4& v0, f32x4& v1) {
-  const f32x2 f = {v0[I0], v1[I1]};
+__device__ __forceinline__ uint32_t split_level(f32x4& v0, f32x4& v1, uint32_t negmask = 0u) {
+  const float x0 = v0[I0], x1 = v1[I1];      // (copies: __builtin_bit_cast of a vector-element lvalue reads element 0)
+  const f32x2 f = {__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x0) ^ negmask),
+                   __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x1) ^ negmask)};
   const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
   v0[I0] = f[0] - __builtin_bit_cast(float, u << 16);
   v1[I1] = f[1] - __builtin_bit_cast(float, u & 0xffff0000u);
@@ -173,15 +177,16 @@ struct SplitRegs {
   u32x4 w;       // packed words waiting for their store
 };
 template <bool KC, int PLANE, int C>
-__device__ __forceinline__ void split_chunk(f32x4 (&r)[2], SplitRegs& st, uint32_t* __restrict__ lds) {
+__device__ __forceinline__ void split_chunk(f32x4 (&r)[2], SplitRegs& st, uint32_t* __restrict__ lds,
+                                            uint32_t negmask) {
   if constexpr (KC) {
     constexpr int q = C / 6, c = C % 6;
     const int f = threadIdx.x + NTH * q;
     uint32_t* dst = lds + (f >> 2) * KC_LD + (f & 3) * 2;
     f32x4& v = r[q];
-    if constexpr (c == 0 || c == 2) st.w[0] = split_level<0, 1>(v, v);
+    if constexpr (c == 0 || c == 2) st.w[0] = split_level<0, 1>(v, v, c == 0 ? negmask : 0u);
     if constexpr (c == 1 || c == 3) {
-      st.w[1] = split_level<2, 3>(v, v);
+      st.w[1] = split_level<2, 3>(v, v, c == 1 ? negmask : 0u);
       *reinterpret_cast<uint2*>(dst + (c / 2) * PLANE) = make_uint2(st.w[0], st.w[1]);
     }
     if constexpr (c == 4)
@@ -193,7 +198,7 @@ __device__ __forceinline__ void split_chunk(f32x4 (&r)[2], SplitRegs& st, uint32
     f32x4& o = r[1];
     if constexpr (C < 8) {
       constexpr int i = C % 4;
-      st.w[i] = split_level<i, i>(e, o);
+      st.w[i] = split_level<i, i>(e, o, C < 4 ? negmask : 0u);
       if constexpr (i == 3) *reinterpret_cast<u32x4*>(dst + (C / 4) * PLANE) = st.w;
     }
     if constexpr (C == 8) { st.w[0] = split_last(e[0], o[0]); st.w[1] = split_last(e[1], o[1]); }
@@ -204,10 +209,11 @@ __device__ __forceinline__ void split_chunk(f32x4 (&r)[2], SplitRegs& st, uint32
   }
 }
 template <bool KC, int PLANE, int C0, int C1>
-__device__ __forceinline__ void split_chunks(f32x4 (&r)[2], SplitRegs& st, uint32_t* __restrict__ lds) {
+__device__ __forceinline__ void split_chunks(f32x4 (&r)[2], SplitRegs& st, uint32_t* __restrict__ lds,
+                                             uint32_t negmask = 0u) {
   if constexpr (C0 < C1) {
-    split_chunk<KC, PLANE, C0>(r, st, lds);
-    split_chunks<KC, PLANE, C0 + 1, C1>(r, st, lds);
+    split_chunk<KC, PLANE, C0>(r, st, lds, negmask);
+    split_chunks<KC, PLANE, C0 + 1, C1>(r, st, lds, negmask);
   }
 }
 
@@ -458,9 +464,37 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     split_chunks<A_KC, PA, 0, 12>(xa, st, buf);
     split_chunks<B_KC, PB, 0, 12>(xb, st, buf + TA);
   };
+  // Accumulator sign groups.  v_mfma_f32_32x32x16_bf16 adds products that are small beside the accumulator with a
+  // bias toward -inf: about -0.004 ulp of the accumulator per MFMA whose products are 2^-9 .. 2^-24 of it, none for
+  // comparable or negligible ones (tools/mfma_bias_probe.hip).  Five of the six MFMAs of a k-slice are such, so the
+  // error of this GEMM, although as small as the fp32 MFMA's element by element, had a MEAN of -0.08 of its rms, and a
+  // sum over ~10^6 of its outputs with non-negative weights (the basis-coefficient gradient) sat 10x further from
+  // float64 than the fp32 MFMA's (tools/gemm_bias_probe.py, test_float64_tie_break).  The bias does not depend on the
+  // sign of what is accumulated, so the k-tiles are cut into four groups and groups 1 and 3 accumulate the NEGATED
+  // product: A goes to LDS negated (one xor per element at the split) and the accumulators change sign at the three
+  // group boundaries and at the end -- 256 VALU per wave and GEMM tile.  The boundaries balance the two signs for
+  // accumulators that stay level, grow like sqrt(k) (random walk) or linearly (a mean): with f = (0.173, 0.5, 0.849),
+  // 2 (f1^p - f2^p + f3^p) - 1 = 0.04, 0.00, 0.00 for p = 1, 1.5, 2.
+  int flip[3] = {1 << 30, 1 << 30, 1 << 30};
+  if (nkt >= 16) {
+    flip[0] = max(2, (int)(0.173f * nkt + 0.5f) & ~1);
+    flip[1] = (nkt / 2 + 1) & ~1;
+    flip[2] = (int)(0.849f * nkt + 0.5f) & ~1;
+  }
+  auto sign_group = [&](int t) { return (t >= flip[0] ? 1 : 0) + (t >= flip[1] ? 1 : 0) + (t >= flip[2] ? 1 : 0); };
+  auto negate_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f - acc[i][j][r];      // (0 - x: zeros stay +0)
+  };
   auto step = [&](int kt, auto parity, auto walk) {
     constexpr int P = decltype(parity)::value;
     constexpr bool WALK = decltype(walk)::value;
+    if (kt == flip[0] || kt == flip[1] || kt == flip[2]) negate_acc();      // tile kt opens a group of the other sign
+    const uint32_t negmask = (sign_group(kt + 1) & 1) ? 0x80000000u : 0u;   // sign of the tile this step stages
     if constexpr (WALK) gwalk(ra[P], rb[P]); else gload(ks + (kt + 2) * BK, ra[P], rb[P]);
     const uint32_t* a_lds = lds + P * (TA + TB);
     const uint32_t* b_lds = a_lds + TA;
@@ -488,7 +522,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
       constexpr int t = NP - TERMS + m / 4, i = (m / 2) % 2, j = m % 2;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_[t]], fb[j][pb_[t]], acc[i][j], 0, 0, 0);
       constexpr int c0 = m * PER < 24 ? m * PER : 24, c1 = (m + 1) * PER < 24 ? (m + 1) * PER : 24;
-      split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt);
+      split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt, negmask);
       split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -517,6 +551,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     step(kt, I0{}, std::false_type{});
     if (kt + 1 < nkt) step(kt + 1, I1{}, std::false_type{});
   }
+  if (nkt > 0 && (sign_group(nkt - 1) & 1)) negate_acc();
 
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
   float* C = g.C + (size_t)z * g.M * g.ldc;

@@ -1323,6 +1323,9 @@ static rgcn_status buffer_of(rgcn_ctx* c, int32_t which, void** p, int64_t* byte
     case RGCN_BUF_ROWPTR: *p = c->g.row_ptr; *bytes = (int64_t)(c->V + 1) * 4; return RGCN_OK;
     case RGCN_BUF_PERM_VERTEX: *p = c->g.permv; *bytes = (int64_t)2 * c->g.E * 4; return RGCN_OK;
     case RGCN_BUF_PERM_RELATION: *p = c->g.permr; *bytes = (int64_t)2 * c->g.E * 4; return RGCN_OK;
+    case RGCN_BUF_RANK_ENERGIES:
+      if (!c->rank_s) RGCN_FAIL(c, RGCN_ERR_STATE, "no score buffer (rgcn_rank_reserve first)");
+      *p = c->rank_s; *bytes = (int64_t)c->rank_max * c->V * 4; return RGCN_OK;
     default: RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown buffer id");
   }
 }

@@ -122,3 +122,54 @@ def gate_consistent_oracle_grads(c, acts, norm="intended", keep=0.8):
                                     c["dcodes"], mode="train", keep_prob=keep, dropout_masks=c["masks"],
                                     norm_mode=norm_mode)
     return grads, flips
+
+
+# ----------------------------------------------------------------------------- float64 tie-break
+import contextlib
+
+
+@contextlib.contextmanager
+def oracle_float64():
+    """The oracle's arithmetic type switched to float64 (every cast in oracle/rgcn_oracle.py goes through its
+    module-level F32 name), restored on exit."""
+    from oracle import rgcn_oracle
+    old = rgcn_oracle.F32
+    rgcn_oracle.F32 = np.float64
+    try:
+        yield
+    finally:
+        rgcn_oracle.F32 = old
+
+
+def float64_grads_at(c, acts, norm="intended", keep=0.8):
+    """float64 reverse mode of the forward pass the ENGINE computed: its own activations (exact fp32 values, hence
+    its own relu gates) go in as float64, so the result is the exact derivative the engine's backward approximates and
+    no gate can sit on different sides.  What is left between the two is fp32 rounding of the backward pass alone,
+    which lets the tolerance drop two orders below the fp32-vs-fp32 comparison's."""
+    norm_mode = {"intended": oracle.NORM_INTENDED, "tf_as_executed": oracle.NORM_TF_AS_EXECUTED,
+                 "none": oracle.NORM_NONE}[norm] if isinstance(norm, str) else norm
+    with oracle_float64():
+        p64 = {k: np.asarray(v, dtype=np.float64) for k, v in c["params"].items()}
+        return oracle.encoder_backward(p64, c["triples"], c["V"], c["L"], c["kind"],
+                                       [np.asarray(a, dtype=np.float64) for a in acts],
+                                       np.asarray(c["dcodes"], dtype=np.float64), mode="train", keep_prob=keep,
+                                       dropout_masks=c["masks"], norm_mode=norm_mode)
+
+
+def float64_forward(c, norm="intended", keep=0.8):
+    norm_mode = {"intended": oracle.NORM_INTENDED, "tf_as_executed": oracle.NORM_TF_AS_EXECUTED,
+                 "none": oracle.NORM_NONE}[norm] if isinstance(norm, str) else norm
+    with oracle_float64():
+        p64 = {k: np.asarray(v, dtype=np.float64) for k, v in c["params"].items()}
+        return oracle.encoder_forward(p64, c["triples"], c["V"], c["L"], c["kind"], mode="train", keep_prob=keep,
+                                      dropout_masks=c["masks"], norm_mode=norm_mode)
+
+
+def error_against(ref64, got):
+    """(max |got - ref| / max |ref|, l2 error / l2 of ref) in float64."""
+    r = np.asarray(ref64, dtype=np.float64)
+    g = np.asarray(got, dtype=np.float64)
+    scale = float(np.abs(r).max()) if r.size else 0.0
+    if scale == 0.0:
+        return (float(np.abs(g).max()) if g.size else 0.0), 0.0
+    return float(np.abs(g - r).max()) / scale, float(np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()))

@@ -67,6 +67,40 @@ def test_ranks_match_reference_definition(native, V, R, d, nb, E, scale):
         eng.close()
 
 
+def test_rank_counts_are_bit_exact_on_the_devices_own_energies(native):
+    """The ranking has a float half (energies: one GEMM, compared with the oracle's within rounding, above) and an
+    integer half (sigmoid -> `>=` counts -> raw / filtered rank).  The integer half is held BIT-EXACT: the energies the
+    device scored are read back (RGCN_BUF_RANK_ENERGIES) and the reference's rank definition
+    (oracle.ranks_from_energies; evaluation.py:148-153) applied to exactly those values must give exactly the
+    device's ranks -- saturated ties (scale 40), repeated queries, filtered lists and both sides included."""
+    for (V, R, d, nb, E, scale) in [(300, 11, 40, 8, 1500, 1.0), (90, 5, 20, 4, 400, 40.0), (1031, 7, 20, 4, 3000, 6.0)]:
+        params, triples, _, _ = make_case(V, R, d, 2, "block", nb, E, seed=E + 1)
+        rng = np.random.RandomState(5)
+        params["W_relation"] = (rng.randn(V, d) * scale).astype(np.float32)
+        queries = triples[rng.choice(len(triples), 120, replace=False)].copy()
+        queries[:7] = queries[3]
+        eng = native.Engine(V, R, d, 2, "block", nb, max_edges=E)
+        try:
+            eng.set_params(params)
+            eng.set_graph(triples)
+            eng.forward(train=False)
+            eng.rank_reserve(len(queries))                        # one chunk: the buffer holds every query's row
+            for object_side in (True, False):
+                known = known_lists(np.concatenate([triples, queries]), object_side)
+                ptr, idx = csr_for(queries, known, object_side)
+                raw, filt = eng.ranks(queries, object_side, ptr, idx)
+                energies = eng.read_buffer(native.BUF_RANK_ENERGIES)
+                assert energies.shape == (len(queries), V)
+                for i, (s, r, o) in enumerate(queries):
+                    gold, key = (o, (s, r)) if object_side else (s, (o, r))
+                    want = oracle.ranks_from_energies(energies[i], gold, known[key])
+                    assert (int(raw[i]), int(filt[i])) == want, (V, object_side, i, raw[i], filt[i], want)
+                if scale > 1:
+                    assert (raw > 1).mean() > 0.2
+        finally:
+            eng.close()
+
+
 def test_sharded_contexts_rank_their_own_query_slices(native):
     """Evaluation on a relation-sharded encoder (SURVEY 8e + f3): two contexts on one device, the test as the
     collective for the test-mode forward, then each rank ranks ITS half of the queries; the concatenation is what
