@@ -16,7 +16,10 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                   this box's host cores on the same minibatch,
   "workloads":    (N = 1, default workload) the same measurement -- value, ms/step, roofline, kernels -- for the
                   other BASELINE.json configurations on one GPU: basis B = 2 / B = 5 (config 3), the WN18 and FB15k
-                  shapes (configs 4 and 5 on one GPU), the 38,001-edge and the 272,115-edge full graphs.
+                  shapes (configs 4 and 5 on one GPU), the 38,001-edge and the 272,115-edge full graphs,
+  "train_steps":  (same run) whole training iterations on the device at the FB15k-237 and FB15k sizes: the minibatch
+                  step train.py launches (edge dropout + negatives + prep + encoder + DistMult + clip + Adam) and
+                  configs[4]'s hipGraph-captured train step, replayed against stream-launched.
 """
 from __future__ import annotations
 
@@ -441,6 +444,97 @@ def measure(workload, args, rk, steps, warmup, full):
     return out
 
 
+TRAIN_STEP_WORKLOADS = {
+    # name: (pool of real triples the 30,000-triple graph batch comes from, V, R)  -- d 500, 2 layers, block kind, 100
+    # blocks; settings/gcn_block.exp: GraphBatchSize 30000, GraphSplitSize 0.5, NegativeSampleRate 10
+    "fb237_block_train_step": ("fb237_valid_test", 14541, 237),
+    "fb15k_block_train_step": ("fb15k_minibatch", 14951, 1345),      # BASELINE.json configs[4]'s space on one GPU
+}
+
+
+def measure_train_step(name, args, steps, warmup):
+    """One whole training iteration on the device (the "next" rows f1, f2, f4 of SURVEY 8 around the hot path), one GPU:
+    (a) rgcn_train_step_minibatch_device, what train.py launches per iteration: exact-k edge dropout of the resident
+        30,000-triple graph batch (15,000 edges kept), 10 negatives per positive (N = 330,000), graph preparation,
+        encoder forward, DistMult loss + gradients, encoder backward, clip, Adam;
+    (b) BASELINE.json configs[4]'s "hipGraph-captured train step": rgcn_train_step_device on a fixed 15,000-edge graph
+        and a fixed batch, captured once and replayed."""
+    import numpy as np
+    from relationprediction_amd import _native
+    from relationprediction_amd.common.shared_functions import init_encoder_params
+    pool_name, V, R = TRAIN_STEP_WORKLOADS[name]
+    d, L, kind, nb, n_batch, keep, rate = 500, 2, "block", 100, 30000, 15000, 10
+    pool = load_graph(pool_name)
+    if pool.shape[0] >= n_batch:
+        batch = np.ascontiguousarray(pool[np.random.RandomState(11).choice(pool.shape[0], n_batch, replace=False)])
+    else:      # fewer real triples than a graph batch: the rest is drawn from their histograms (as graph B, SURVEY 8d)
+        extra = synthetic_from_histograms(pool, n_batch - pool.shape[0], seed=11)
+        batch = np.ascontiguousarray(np.concatenate([pool, extra]).astype(np.int32))
+    N = n_batch * (rate + 1)
+    eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=n_batch)
+    out = {"workload": name, "graph_batch": n_batch, "graph_edges": keep, "decoder_triples": N, "steps": steps,
+           "entities": V, "relations": R}
+    held = []
+    try:
+        eng.set_gemm_mode(args.gemm_mode)
+        eng.set_params(init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1)))
+        eng.decoder_reserve(N)
+        eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
+        batch_dev = eng.to_device(batch)
+        X = _native.DeviceBuffer(eng, 12 * N)
+        Y = _native.DeviceBuffer(eng, 4 * N)
+        held += [batch_dev, X, Y]
+
+        def run(n, seed0):
+            for i in range(n):
+                eng.train_step_minibatch_device(batch_dev, n_batch, keep, seed0 + i, rate, seed0 + i, X, Y,
+                                                seed=seed0 + i, reg_param=0.01)
+        run(warmup, 100)
+        eng.sync()
+        t0 = time.perf_counter()
+        run(steps, 1000)
+        eng.sync()
+        wall = time.perf_counter() - t0
+        loss = eng.loss()
+        out["minibatch_step"] = {"ms_per_step": round(wall * 1e3 / steps, 4), "edges_per_s": round(keep * steps / wall, 1),
+                                 "triples_per_s": round(N * steps / wall, 1), "loss_after": round(loss, 6),
+                                 "entry_point": "rgcn_train_step_minibatch_device"}
+        # (b) captured: the graph the last step kept, the batch the last step drew
+        graph = eng.to_device(eng.graph_edges())
+        held.append(graph)
+        eng.train_step_device(graph, keep, X, Y, N, seed=1, reg_param=0.01)
+        eng.sync()
+        eng.capture_begin()
+        eng.train_step_device(graph, keep, X, Y, N, seed=2, reg_param=0.01)
+        gid = eng.capture_end()
+        for _ in range(warmup):
+            eng.graph_launch(gid)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.graph_launch(gid)
+        eng.sync()
+        wall_g = time.perf_counter() - t0
+        for i in range(warmup):
+            eng.train_step_device(graph, keep, X, Y, N, seed=50 + i, reg_param=0.01)
+        eng.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.train_step_device(graph, keep, X, Y, N, seed=100 + i, reg_param=0.01)
+        eng.sync()
+        wall_s = time.perf_counter() - t0
+        out["captured_step"] = {"ms_per_step_hipgraph_replay": round(wall_g * 1e3 / steps, 4),
+                                "ms_per_step_stream_launched": round(wall_s * 1e3 / steps, 4),
+                                "entry_point": "rgcn_train_step_device inside rgcn_capture_begin / _end",
+                                "loss_after": round(eng.loss(), 6)}
+        eng.graph_destroy(gid)
+    finally:
+        for b in held:
+            b.free()
+        eng.close()
+    return out
+
+
 def main():
     args = parse_args()
     rk = Ranks(args)
@@ -455,8 +549,13 @@ def main():
             for drop in ("cpu_baseline", "fp32_mfma_reference", "higher_is_better", "vs_baseline"):
                 o.pop(drop, None)
             extras.append(o)
+    train_steps = []
+    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
+        for w in TRAIN_STEP_WORKLOADS:
+            train_steps.append(measure_train_step(w, args, args.extra_steps, min(args.warmup, 5)))
     if rk.rank == 0:
         out["workloads"] = extras
+        out["train_steps"] = train_steps
     if rk.world > 1 and rk.rank == 0 and os.path.exists(rk.rdv_path):
         os.remove(rk.rdv_path)
 

@@ -15,6 +15,11 @@ def line(o):
 print(line(d))
 for o in d.get("workloads", []):
     print(line(o))
+for t in d.get("train_steps", []):
+    m, c = t.get("minibatch_step", {}), t.get("captured_step", {})
+    print("%-24s minibatch step %7.3f ms (%.2f M edges/s, %.0f M triples/s)   captured step: hipGraph replay %7.3f ms, streams %7.3f ms" % (
+        t["workload"], m.get("ms_per_step", 0), m.get("edges_per_s", 0) / 1e6, m.get("triples_per_s", 0) / 1e6,
+        c.get("ms_per_step_hipgraph_replay", 0), c.get("ms_per_step_stream_launched", 0)))
 print("cpu", d.get("cpu_baseline"))
 print("fp32 mfma reference", d.get("fp32_mfma_reference"))
 for o in [d] + (d.get("workloads", []) if "-v" in sys.argv else []):

@@ -21,6 +21,8 @@ def line(o):
 print(line(d))
 for o in d.get("workloads", []):
     print(line(o))
+for t in d.get("train_steps", []):
+    print("  ", t["workload"], t.get("minibatch_step"), t.get("captured_step"))
 print("cpu", d.get("cpu_baseline"))
 for k in d["kernels"]:
     print("   %-22s x%.0f %7.1f us (pipelined %7.1f) %s frac %.3f" % (k["kernel"], k["launches_per_step"], k["avg_us"], k["avg_us_in_pipeline"], k["bound"], k["frac"]))
