@@ -335,3 +335,45 @@ def test_unsupported_metric_and_checkpoint_directory(tmp_path):
     m2 = M([W("w%d" % i, np.zeros(2, np.float32)) for i in range(120)])
     m2.load(str(tmp_path / "models" / "Run-0.npz"))
     assert all(np.array_equal(a.v, b.v) for a, b in zip(m.ws, m2.ws))
+
+
+def test_reference_layout_aliases_the_reference_module_names():
+    """A driver written against the reference's top-level module names (it runs from inside code/) keeps them:
+    `import relationprediction_amd.reference_layout` registers `model`, `common.*`, `encoders.*`, `decoders.*`,
+    `extras.*`, `optimization.optimize` as this package's mirrors; what is not mirrored stays an ImportError; a name
+    already imported from another tree is never replaced.  (In a subprocess: the aliases are process-wide.)"""
+    import os
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, types
+sys.path.insert(0, %r)
+import relationprediction_amd.reference_layout as rl
+from common import settings_reader, io, model_builder, optimizer_parameter_parser, auxilliaries, evaluation
+from encoders.message_gcns.gcn_basis import BasisGcn
+from encoders.message_gcns.gcn_basis_concat import ConcatGcn
+from encoders.relation_embedding import RelationEmbedding
+from encoders.affine_transform import AffineTransform
+from decoders.bilinear_diag import BilinearDiag
+from extras.graph_representations import Representation
+from model import Model
+import relationprediction_amd.model, relationprediction_amd.common.model_builder as mine
+assert Model is relationprediction_amd.model.Model and model_builder is mine
+try:
+    import encoders.bipartite_gcn          # a TensorFlow-only encoder of the reference: not mirrored
+    raise SystemExit("unmirrored module imported")
+except ImportError:
+    pass
+rl.uninstall()
+assert "common" not in sys.modules and "model" not in sys.modules
+sys.modules["model"] = types.ModuleType("model")      # somebody else's `model`
+try:
+    rl.install()
+    raise SystemExit("install() replaced a foreign module")
+except ImportError as e:
+    assert "refusing" in str(e)
+print("aliases ok")
+''' % root
+    r = subprocess.run([_sys.executable, "-B", "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "aliases ok" in r.stdout, (r.stdout, r.stderr)
