@@ -162,6 +162,40 @@ def traffic_table(workload):
     return {}, None
 
 
+def kernel_table(prof, steps, args, in_pipeline=None):
+    """rgcn_profile_get rows -> per-kernel accounting: exclusive average duration, algorithmic bytes / flops per launch
+    (what the launch site declares: DESIGN.md section 4), the roofline that bounds it and the achieved fraction."""
+    in_pipeline = in_pipeline or {}
+    kernels = []
+    for p in prof:
+        if p["calls"] == 0:
+            continue
+        avg_ms = p["total_ms"] / p["calls"]
+        by, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
+        t_hbm = by / (PEAK_HBM_GBS * 1e9)
+        # flops the matrix cores execute: the split arithmetic issues `terms` bf16 MFMAs per fp32 product
+        terms = args.gemm_mode if args.gemm_mode else 1
+        mfma_peak = PEAK_BF16_MFMA_TFS if args.gemm_mode else PEAK_F32_MFMA_TFS
+        t_mfma = terms * fl / (mfma_peak * 1e12)
+        bound = "mfma" if t_mfma > t_hbm else "hbm"
+        sec = max(avg_ms, 1e-9) * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = terms * fl / sec / 1e12, mfma_peak, "TFLOP/s"
+        else:
+            ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+        kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / steps,
+                        "avg_us": round(avg_ms * 1e3, 2),
+                        "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
+                        "ms_per_step": round(p["total_ms"] / steps, 4),
+                        "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
+        if bound == "mfma":
+            kernels[-1]["mfma_dtype"] = "bf16 (x%d exact operand split of fp32)" % terms if args.gemm_mode else "f32"
+            kernels[-1]["executed_flops"] = terms * fl
+            kernels[-1]["fp32_equivalent_tflops"] = round(fl / sec / 1e12, 2)
+    return kernels
+
+
 def measure(workload, args, rk, steps, warmup, full):
     """One workload on this rank's engine: timed steps (barrier + sync on both sides, max over ranks), then the
     per-kernel passes.  full = the headline extras (fp32-MFMA reference run, CPU baseline)."""
@@ -304,32 +338,7 @@ def measure(workload, args, rk, steps, warmup, full):
         prof = eng.profile()
         eng.profile_enable(False)
         eng.set_overlap(os.environ.get("RGCN_STREAMS", "1") != "0")
-        for p in prof:
-            if p["calls"] == 0:
-                continue
-            avg_ms = p["total_ms"] / p["calls"]
-            by, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
-            t_hbm = by / (PEAK_HBM_GBS * 1e9)
-            # flops the matrix cores execute: the split arithmetic issues `terms` bf16 MFMAs per fp32 product
-            terms = args.gemm_mode if args.gemm_mode else 1
-            mfma_peak = PEAK_BF16_MFMA_TFS if args.gemm_mode else PEAK_F32_MFMA_TFS
-            t_mfma = terms * fl / (mfma_peak * 1e12)
-            bound = "mfma" if t_mfma > t_hbm else "hbm"
-            sec = max(avg_ms, 1e-9) * 1e-3
-            if bound == "mfma":
-                ach, peak, unit = terms * fl / sec / 1e12, mfma_peak, "TFLOP/s"
-            else:
-                ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-            kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / steps,
-                            "avg_us": round(avg_ms * 1e3, 2),
-                            "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
-                            "ms_per_step": round(p["total_ms"] / steps, 4),
-                            "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                            "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
-            if bound == "mfma":
-                kernels[-1]["mfma_dtype"] = "bf16 (x%d exact operand split of fp32)" % terms if args.gemm_mode else "f32"
-                kernels[-1]["executed_flops"] = terms * fl
-                kernels[-1]["fp32_equivalent_tflops"] = round(fl / sec / 1e12, 2)
+        kernels = kernel_table(prof, steps, args, in_pipeline)
         traffic, traffic_src = traffic_table(workload)
         for k in kernels:
             pref = KERNEL_OF_TAG.get(k["kernel"])
@@ -523,6 +532,22 @@ def measure_train_step(name, args, steps, warmup):
             eng.train_step_device(graph, keep, X, Y, N, seed=100 + i, reg_param=0.01)
         eng.sync()
         wall_s = time.perf_counter() - t0
+        if not args.no_kernel_profile:
+            # exclusive durations (side streams off) of every kernel of the stream-launched step, with the algorithmic
+            # bytes / flops its launch site declares: the decoder, optimizer and edge-dropout kernels' own rooflines
+            eng.set_overlap(False)
+            eng.profile_reset()
+            eng.profile_enable(True)
+            run(steps, 3000)
+            eng.sync()
+            prof = eng.profile()
+            eng.profile_enable(False)
+            eng.set_overlap(os.environ.get("RGCN_STREAMS", "1") != "0")
+            ks = kernel_table(prof, steps, args)
+            ks.sort(key=lambda k: -k["ms_per_step"])
+            out["minibatch_step"]["kernels"] = [
+                {f: k[f] for f in ("kernel", "launches_per_step", "avg_us", "ms_per_step", "bound", "achieved", "unit",
+                                   "frac")} for k in ks]
         out["captured_step"] = {"ms_per_step_hipgraph_replay": round(wall_g * 1e3 / steps, 4),
                                 "ms_per_step_stream_launched": round(wall_s * 1e3 / steps, 4),
                                 "entry_point": "rgcn_train_step_device inside rgcn_capture_begin / _end",

@@ -279,8 +279,9 @@ __global__ void k_build_msgs(const int32_t* __restrict__ tri, int E, int V, int 
 // `graph_edges`, so degrees / normalisation see the kept edges alone while the decoder keeps every batch
 // edge as a positive (H9).  Here: every batch edge e gets the 64-bit key (40 random bits of a counter-based generator
 // keyed by (seed, e)) << 24 | e -- all keys distinct -- and the k smallest keys are kept, which is a uniform k-subset.
-// The k-th smallest key is found by an 8-pass radix select (one LDS histogram per byte, keys recomputed on the fly,
-// nothing stored), then the kept edges are compacted in batch order.  One workgroup, one launch, deterministic.
+// The k-th smallest key is found by a radix select (one LDS histogram per byte, most significant first, keys recomputed
+// on the fly, nothing stored; as soon as the wanted bin holds a single key it is fetched directly), then the kept edges
+// are compacted in batch order with one block-wide scan.  One workgroup, one launch, deterministic.
 // keep_mask != nullptr: the caller's 0/1 choice instead of the draw (parity tests inject the reference's set).
 __device__ __forceinline__ uint64_t dropout_edge_key(uint64_t seed, uint32_t e) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)e + 0x51ED27ull);
@@ -290,76 +291,120 @@ __device__ __forceinline__ uint64_t dropout_edge_key(uint64_t seed, uint32_t e) 
   return (z & 0xFFFFFFFFFF000000ull) | (uint64_t)e;
 }
 
+// CACHED: n <= 32 x 1024 -- every thread computes the keys of its <= 32 edges ONCE and keeps them in registers (the
+// 64-bit generator is most of the kernel's work; the sweeps below then only compare); otherwise they are recomputed.
+template <bool CACHED>
 __global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict__ batch, int n, int keep, uint64_t seed,
                                                        const uint8_t* __restrict__ keep_mask,
                                                        int32_t* __restrict__ out, int32_t* errflag) {
   __shared__ uint32_t hist[256];
-  __shared__ uint64_t prefix_s;
-  __shared__ uint32_t want_s;
-  __shared__ int32_t wsum[16];
-  __shared__ int32_t base_s;
+  __shared__ uint32_t wtot[16];
+  __shared__ uint64_t prefix_s, thresh_s;
+  __shared__ uint32_t want_s, unique_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // thread t owns the contiguous edges [e_lo, e_hi): the compaction below is then ONE block-wide scan
+  const int per = (n + 1023) / 1024;
+  const int e_lo = min(n, tid * per), e_hi = min(n, e_lo + per);
   uint64_t thresh = 0;      // keep iff key <= thresh (only used without a mask)
-  if (keep_mask == nullptr && keep > 0 && keep < n) {
-    if (tid == 0) { prefix_s = 0; want_s = (uint32_t)keep; }
+  constexpr int KP = CACHED ? 32 : 1;
+  uint64_t kc[KP];
+  const bool draw = keep_mask == nullptr && keep > 0 && keep < n;
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) kc[i] = (draw && e_lo + i < e_hi) ? dropout_edge_key(seed, (uint32_t)(e_lo + i)) : 0ull;
+  }
+  // f(key, e) for every edge of this thread
+  auto for_each_key = [&](auto&& f) {
+    if constexpr (CACHED) {
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        if (e_lo + i < e_hi) f(kc[i], e_lo + i);
+    } else {
+      for (int e = e_lo; e < e_hi; ++e) f(dropout_edge_key(seed, (uint32_t)e), e);
+    }
+  };
+  if (draw) {
+    if (tid == 0) { prefix_s = 0; want_s = (uint32_t)keep; unique_s = 0; thresh_s = 0; }
+    // radix select of the keep-th smallest key, most significant byte first.  The keys are 40 random bits | the edge
+    // index, so after two or three bytes the wanted bin holds ONE key: it is then fetched directly instead of being
+    // pinned down byte by byte (8 sweeps -> typically 3).
     for (int pass = 0; pass < 8; ++pass) {
       const int shift = 8 * (7 - pass);
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const uint64_t prefix = prefix_s;
-      for (int e = tid; e < n; e += 1024) {
-        const uint64_t key = dropout_edge_key(seed, (uint32_t)e);
-        const bool in = pass == 0 || (key >> (shift + 8)) == prefix;
-        if (in) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
-      }
+      for_each_key([&](uint64_t key, int) {
+        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+      });
       __syncthreads();
-      if (tid == 0) {           // 256 bins: the bin in which the running count reaches what is still wanted
-        uint32_t want = want_s, run = 0;
-        int b = 0;
-        for (; b < 255; ++b) {
-          if (run + hist[b] >= want) break;
-          run += hist[b];
+      // the bin in which the running count reaches what is still wanted: inclusive scan over the 256 bins by four waves
+      uint32_t h = 0, incl = 0;
+      if (tid < 256) {
+        h = hist[tid];
+        incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
         }
-        prefix_s = (prefix << 8) | (uint64_t)b;
-        want_s = want - run;
+        if (lane == 63) wtot[wid] = incl;
       }
       __syncthreads();
-    }
-    thresh = prefix_s;
-  }
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  // stable compaction, 1024 edges per round
-  for (int e0 = 0; e0 < n; e0 += 1024) {
-    const int e = e0 + tid;
-    bool kept = false;
-    if (e < n) {
-      if (keep_mask != nullptr) kept = keep_mask[e] != 0;
-      else kept = keep >= n || (keep > 0 && dropout_edge_key(seed, (uint32_t)e) <= thresh);
-    }
-    const unsigned long long vote = __ballot(kept);
-    const int rank = __popcll(vote & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wid] = __popcll(vote);
-    __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
-      if (w < wid) before += wsum[w];
-      total += wsum[w];
-    }
-    const int base = base_s;
-    if (kept) {
-      const int slot = base + before + rank;
-      if (slot < keep) {
-        out[3 * slot] = batch[3 * e];
-        out[3 * slot + 1] = batch[3 * e + 1];
-        out[3 * slot + 2] = batch[3 * e + 2];
+      if (tid < 256) {
+        for (int w = 0; w < wid; ++w) incl += wtot[w];
+        const uint32_t want = want_s, excl = incl - h;
+        if ((excl < want && incl >= want) || (tid == 255 && incl < want)) {
+          prefix_s = (prefix << 8) | (uint64_t)tid;
+          want_s = want - excl;
+          unique_s = (h == 1 && pass < 7) ? 1u : 0u;
+        }
       }
+      __syncthreads();
+      if (unique_s) {           // uniform: one key carries the new prefix -- fetch it
+        const uint64_t p2 = prefix_s;
+        for_each_key([&](uint64_t key, int) {
+          if ((key >> shift) == p2) thresh_s = key;
+        });
+        __syncthreads();
+        break;
+      }
+      if (pass == 7 && tid == 0) thresh_s = prefix_s;
     }
     __syncthreads();
-    if (tid == 0) base_s = base + total;
-    __syncthreads();
+    thresh = thresh_s;
   }
-  if (tid == 0 && base_s != keep) atomicOr(errflag, 4);     // a mask that does not hold exactly `keep` ones
+  // stable compaction: per-thread counts over its own edges, one exclusive scan over the 1024 threads, then the writes
+  auto kept_at = [&](uint64_t key, int e) -> bool {
+    if (keep_mask != nullptr) return keep_mask[e] != 0;
+    return keep >= n || (keep > 0 && key <= thresh);
+  };
+  uint32_t cnt = 0;
+  for_each_key([&](uint64_t key, int e) { cnt += kept_at(key, e) ? 1u : 0u; });
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();             // (wtot is reused)
+  if (lane == 63) wtot[wid] = incl;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wid) before += wtot[w];
+    total += wtot[w];
+  }
+  int slot = (int)(before + incl - cnt);
+  for_each_key([&](uint64_t key, int e) {
+    if (!kept_at(key, e)) return;
+    if (slot < keep) {
+      out[3 * slot] = batch[3 * e];
+      out[3 * slot + 1] = batch[3 * e + 1];
+      out[3 * slot + 2] = batch[3 * e + 2];
+    }
+    ++slot;
+  });
+  if (tid == 0 && (int)total != keep) atomicOr(errflag, 4);     // a mask that does not hold exactly `keep` ones
 }
 
 int bits_for(uint32_t max_value) {
@@ -533,8 +578,12 @@ rgcn_status graph_build_dropout(rgcn_ctx* c, const int32_t* batch, int64_t n, in
   GraphBufs& g = c->g;
   if (n > 0) {
     ProfScope ps(c, "prep_edge_dropout", 12.0 * n + 12.0 * keep, 0);
-    hipLaunchKernelGGL(k_edge_dropout, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed, keep_mask,
-                       g.triples, g.errflag);
+    if (n <= 32 * 1024)
+      hipLaunchKernelGGL(k_edge_dropout<true>, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed,
+                         keep_mask, g.triples, g.errflag);
+    else
+      hipLaunchKernelGGL(k_edge_dropout<false>, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed,
+                         keep_mask, g.triples, g.errflag);
     RGCN_HIP(c, hipGetLastError());
   }
   return graph_build(c, g.triples, keep);

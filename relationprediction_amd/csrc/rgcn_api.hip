@@ -179,6 +179,36 @@ static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes
   return RGCN_OK;
 }
 
+// Process-wide stream pool.  ROCm hands a new stream its hardware queue round-robin, and objects that outlive a
+// context (an instantiated hipGraph with a forked branch keeps internal streams) shift that assignment: a context
+// created LATER in the same process could find two of its four streams on one hardware queue, and its stream-launched
+// step ran at half speed with the GPU idle between kernels (seen in bench.py: the second train-step workload at 2.7 ms
+// against 1.3 ms in a fresh process, graph replay unaffected).  Streams are therefore kept when a context is destroyed
+// and handed to the next one on that device: every context of a process runs on the streams -- and the queue
+// assignment -- of the first.  Key: (device, priority).  Never destroyed (the runtime goes first at exit).
+namespace {
+struct PooledStream { int device; int priority; hipStream_t s; };
+std::mutex g_stream_pool_mu;
+std::vector<PooledStream> g_stream_pool;
+}  // namespace
+static hipError_t acquire_stream(int device, int priority, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+      if (g_stream_pool[i].device == device && g_stream_pool[i].priority == priority) {
+        *out = g_stream_pool[i].s;
+        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, priority);
+}
+static void release_stream(int device, int priority, hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+  g_stream_pool.push_back(PooledStream{device, priority, s});
+}
+
 static void free_all(rgcn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
@@ -210,7 +240,7 @@ static void free_all(rgcn_ctx* c) {
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
   for (int k = 0; k < kAuxStreams; ++k) {
-    if (k < 2 && c->aux[k]) (void)hipStreamDestroy(c->aux[k]);     // aux[2] is the prefetch stream, destroyed below
+    if (k < 2) release_stream(c->cfg.device, c->aux_priority, c->aux[k]);     // aux[2] is the prefetch stream, below
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -224,8 +254,8 @@ static void free_all(rgcn_ctx* c) {
     (void)hipHostFree(c->stage_host);
     for (hipEvent_t e : c->stage_done) if (e) (void)hipEventDestroy(e);
   }
-  if (c->pf_stream) (void)hipStreamDestroy(c->pf_stream);
-  if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
+  release_stream(c->cfg.device, c->pf_priority, c->pf_stream);
+  release_stream(c->cfg.device, 0, c->main_stream);
   delete c;
 }
 
@@ -270,7 +300,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   c->row_hi = std::min(c->V, c->row_lo + c->shard_rows);
 
   RGCN_HIP(c, hipSetDevice(f.device));
-  RGCN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  RGCN_HIP(c, acquire_stream(f.device, 0, &c->stream));
   c->main_stream = c->stream;
   {
     // side streams get the highest priority: their short HBM-bound kernels should claim wave slots
@@ -283,11 +313,12 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     // both of its jobs -- the next minibatch's graph prep and the decoder's relation gradient -- are fillers.  A
     // fifth HIP stream would share a hardware queue with one of the other four (ROCm maps streams onto 4 queues by
     // default) and serialise against it: measured, the pipelined encoder step went from 0.60 to 0.97 ms.
-    for (int k = 0; k < 2; ++k)
-      RGCN_HIP(c, hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, use_prio ? prio_hi : prio_lo));
+    c->aux_priority = use_prio ? prio_hi : prio_lo;
+    for (int k = 0; k < 2; ++k) RGCN_HIP(c, acquire_stream(f.device, c->aux_priority, &c->aux[k]));
     const char* pp = getenv("RGCN_PF_PRIO");
     const bool pf_low = !(pp && atoi(pp) == 1);
-    RGCN_HIP(c, hipStreamCreateWithPriority(&c->pf_stream, hipStreamNonBlocking, pf_low ? prio_lo : 0));
+    c->pf_priority = pf_low ? prio_lo : 0;
+    RGCN_HIP(c, acquire_stream(f.device, c->pf_priority, &c->pf_stream));
     c->aux[2] = c->pf_stream;
     for (int k = 0; k < kAuxStreams; ++k)
       RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
@@ -1039,12 +1070,20 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
   // The decoder batch's CSRs depend on X only.  They are built on side stream 1, forked at the START of the step,
   // but enqueued AFTER the encoder's prep and forward: their two sorts are ~45 launches of a few microseconds, and
   // queued first they kept the host from feeding the main stream for the first 0.3 ms of every step.
-  if (c->use_aux) {
+  // A captured step is a single chain (rgcn_capture_begin) with ONE exception, this fork: the preparation is ~0.15 ms
+  // of small launches that nothing in the encoder's forward pass depends on, worth far more than the two cross-stream
+  // edges it puts into the graph.
+  const bool fork_in_capture = c->capturing && c->use_aux_before_capture && c->step_begin_in_capture && c->world == 1;
+  if (c->use_aux || fork_in_capture) {
     RGCN_HIP(c, hipStreamWaitEvent(c->aux[1], c->ev_step_begin, 0));
     c->stream = c->aux[1];
     const rgcn_status ps = decoder_prepare(c, X_dev, N);
     c->stream = c->main_stream;
     RGCN_TRY(ps);
+    if (fork_in_capture) {       // (stream_join is a no-op while the side streams are switched off)
+      RGCN_HIP(c, hipEventRecord(c->ev_join[1], c->aux[1]));
+      RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[1], 0));
+    }
   } else {
     RGCN_TRY(decoder_prepare(c, X_dev, N));
   }

@@ -279,6 +279,7 @@ struct rgcn_ctx {
   rgcn::GraphBufs g;                     // ACTIVE graph structures
   rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
   hipStream_t pf_stream = nullptr;       // stream of rgcn_prefetch_graph_device
+  int aux_priority = 0, pf_priority = 0;  // what the side / prefetch streams were created with (stream pool key)
   // pinned staging ring of rgcn_copy_to_device_async: the caller's memory is copied here during the call, the
   // transfer itself is stream-ordered and the host does not wait for it
   static constexpr int kStageSlots = 8;

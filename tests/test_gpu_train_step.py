@@ -335,6 +335,29 @@ def test_device_edge_dropout_semantics(native):
             draws.setdefault((seed, keep), []).append(idx)
         a, b = draws[(1, 1500)]
         assert np.array_equal(a, b) and not np.array_equal(a, draws[(2, 1500)][0])
+        # the draw IS "the k smallest of the keys (40 bits of splitmix64(seed, e)) << 24 | e" (graph_prep.hip), on both
+        # code paths of the kernel: keys kept in registers (n <= 32,768) and recomputed per sweep (larger batches)
+        def smallest_keys(seed, n_edges, k):
+            e = np.arange(n_edges, dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (e + np.uint64(0x51ED27))
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                z = z ^ (z >> np.uint64(31))
+            keys = (z & np.uint64(0xFFFFFFFFFF000000)) | e
+            return np.sort(np.argsort(keys, kind="stable")[:k])
+        assert np.array_equal(a, smallest_keys(1, n, 1500))
+        big_n = 40000
+        big = _unique_batch(np.random.RandomState(4), V, R, big_n)
+        big_eng = native.Engine(V, R, d, L, "block", nb, max_edges=big_n)
+        try:
+            bb = big_eng.to_device(big)
+            for seed, keep in ((5, 20000), (6, 123), (6, big_n - 1)):
+                big_eng.set_graph_dropout_device(bb, big_n, keep, seed=seed)
+                np.testing.assert_array_equal(big_eng.graph_edges(), big[smallest_keys(seed, big_n, keep)])
+            bb.free()
+        finally:
+            big_eng.close()
         # the drawn graph behaves exactly like the same rows fed directly
         eng.set_graph_dropout_device(bd, n, 1500, seed=1)
         eng.forward(train=False)
