@@ -395,15 +395,33 @@ __global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict
     total += wtot[w];
   }
   int slot = (int)(before + incl - cnt);
-  for_each_key([&](uint64_t key, int e) {
-    if (!kept_at(key, e)) return;
-    if (slot < keep) {
-      out[3 * slot] = batch[3 * e];
-      out[3 * slot + 1] = batch[3 * e + 1];
-      out[3 * slot + 2] = batch[3 * e + 2];
+  if constexpr (CACHED) {
+    // the kept edge ids go to LDS in output order (e < 32,768: 16 bits), then the rows are copied slot by slot:
+    // consecutive lanes write consecutive rows and read rows a few apart (a thread copying its own run of rows touched
+    // 64 cache lines per wave instruction and was 2/3 of the kernel)
+    extern __shared__ uint16_t sel[];
+    for_each_key([&](uint64_t key, int e) {
+      if (!kept_at(key, e)) return;
+      if (slot < keep) sel[slot] = (uint16_t)e;
+      ++slot;
+    });
+    __syncthreads();
+    const int ncopy = min((int)total, keep);
+    for (int i = tid; i < 3 * ncopy; i += 1024) {
+      const int sl = i / 3, f = i - 3 * sl;
+      out[i] = batch[3 * (int)sel[sl] + f];
     }
-    ++slot;
-  });
+  } else {
+    for_each_key([&](uint64_t key, int e) {
+      if (!kept_at(key, e)) return;
+      if (slot < keep) {
+        out[3 * slot] = batch[3 * e];
+        out[3 * slot + 1] = batch[3 * e + 1];
+        out[3 * slot + 2] = batch[3 * e + 2];
+      }
+      ++slot;
+    });
+  }
   if (tid == 0 && (int)total != keep) atomicOr(errflag, 4);     // a mask that does not hold exactly `keep` ones
 }
 
@@ -578,9 +596,16 @@ rgcn_status graph_build_dropout(rgcn_ctx* c, const int32_t* batch, int64_t n, in
   GraphBufs& g = c->g;
   if (n > 0) {
     ProfScope ps(c, "prep_edge_dropout", 12.0 * n + 12.0 * keep, 0);
-    if (n <= 32 * 1024)
-      hipLaunchKernelGGL(k_edge_dropout<true>, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed,
-                         keep_mask, g.triples, g.errflag);
+    if (n <= 32 * 1024) {
+      static bool configured = false;      // up to 64 KB of kept-edge ids beside the static 1.2 KB
+      if (!configured) {
+        RGCN_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_dropout<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024));
+        configured = true;
+      }
+      hipLaunchKernelGGL(k_edge_dropout<true>, dim3(1), dim3(1024), 2 * (size_t)std::max<int64_t>(keep, 1), c->stream,
+                         batch, (int)n, (int)keep, seed, keep_mask, g.triples, g.errflag);
+    }
     else
       hipLaunchKernelGGL(k_edge_dropout<false>, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed,
                          keep_mask, g.triples, g.errflag);
