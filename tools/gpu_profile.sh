@@ -11,9 +11,9 @@ ROOTDIR=$GRAFT_REPO_ROOT
 OUT=$ROOTDIR/gpurun_out/prof_${TAG}_${WL}${SUF}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-( cd $ROOTDIR && rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD ) > $OUT/trace.log 2>&1; echo "trace rc=$?"
-( cd $ROOTDIR && rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $CMD ) > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
-( cd $ROOTDIR && rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $CMD ) > $OUT/pmc_write.log 2>&1; echo "write rc=$?"
+( cd $ROOTDIR && timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD ) > $OUT/trace.log 2>&1; echo "trace rc=$?"
+( cd $ROOTDIR && timeout 180 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $CMD ) > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+( cd $ROOTDIR && timeout 180 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $CMD ) > $OUT/pmc_write.log 2>&1; echo "write rc=$?"
 cd $ROOTDIR
 python tools/rocprof_summary.py $OUT gpurun_out/${TAG}_rocprof_${WL}${SUF}.md "$([ "$MODE" = serial ] && echo 'RGCN_STREAMS=0 RGCN_BENCH_PREFETCH=0 ')$CMD" | head -40
 # keep the merge small: drop the per-dispatch databases, the summaries are what is kept
