@@ -188,16 +188,23 @@ static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes
 // assignment -- of the first.  Key: (device, priority).  Never destroyed (the runtime goes first at exit).
 namespace {
 struct PooledStream { int device; int priority; hipStream_t s; };
-std::mutex g_stream_pool_mu;
-std::vector<PooledStream> g_stream_pool;
+struct StreamPool {
+  std::mutex mu;
+  std::vector<PooledStream> free_streams;
+};
+StreamPool& stream_pool() {          // allocated once, never destroyed: usable from whatever runs at process exit
+  static StreamPool* pool = new StreamPool();
+  return *pool;
+}
 }  // namespace
 static hipError_t acquire_stream(int device, int priority, hipStream_t* out) {
   {
-    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-    for (size_t i = 0; i < g_stream_pool.size(); ++i)
-      if (g_stream_pool[i].device == device && g_stream_pool[i].priority == priority) {
-        *out = g_stream_pool[i].s;
-        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    for (size_t i = 0; i < sp.free_streams.size(); ++i)
+      if (sp.free_streams[i].device == device && sp.free_streams[i].priority == priority) {
+        *out = sp.free_streams[i].s;
+        sp.free_streams.erase(sp.free_streams.begin() + (long)i);
         return hipSuccess;
       }
   }
@@ -205,8 +212,9 @@ static hipError_t acquire_stream(int device, int priority, hipStream_t* out) {
 }
 static void release_stream(int device, int priority, hipStream_t s) {
   if (!s) return;
-  std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-  g_stream_pool.push_back(PooledStream{device, priority, s});
+  StreamPool& sp = stream_pool();
+  std::lock_guard<std::mutex> lk(sp.mu);
+  sp.free_streams.push_back(PooledStream{device, priority, s});
 }
 
 static void free_all(rgcn_ctx* c) {
