@@ -220,6 +220,13 @@ static void release_stream(int device, int priority, hipStream_t s) {
 static void free_all(rgcn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
+  if (c->capturing && c->main_stream) {      // destroyed in mid-capture: the streams go back to the pool in a usable state
+    hipGraph_t dangling = nullptr;
+    (void)hipStreamEndCapture(c->main_stream, &dangling);
+    if (dangling) (void)hipGraphDestroy(dangling);
+    (void)hipGetLastError();
+    c->capturing = false;
+  }
   if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
   for (int k = 0; k < kAuxStreams; ++k)
     if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);

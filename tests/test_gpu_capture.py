@@ -161,3 +161,43 @@ def test_capture_on_a_sharded_context_is_refused_by_default(native):
         assert "RGCN_CAPTURE_SHARDED" in str(err.value)
     finally:
         eng.close()
+
+
+def test_context_destroyed_in_mid_capture_leaves_usable_streams(native):
+    """Streams outlive their context (process-wide pool, rgcn_api.hip): a context closed between rgcn_capture_begin and
+    rgcn_capture_end must end the capture first, or the next context on this device would inherit a capturing stream.
+    The next context runs a step and a capture of its own and gets the plain context's result bit for bit."""
+    import helpers
+    V, R, d, L, nb, E = 80, 6, 20, 2, 4, 300
+    params, triples, _, dcodes = helpers.make_case(V, R, d, L, "block", nb, E, seed=8)
+
+    def codes_after_step(eng):
+        eng.set_params(params)
+        t, dc = eng.to_device(triples), eng.to_device(dcodes)
+        eng.step_device(t, E, dc, train=True, seed=3)
+        out = eng.codes()
+        t.free(); dc.free()
+        return out
+    ref_eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        want = codes_after_step(ref_eng)
+    finally:
+        ref_eng.close()
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    eng.set_params(params)
+    t, dc = eng.to_device(triples), eng.to_device(dcodes)
+    eng.capture_begin()
+    eng.step_device(t, E, dc, train=True, seed=3)
+    eng.close()                                               # in mid-capture (device buffers die with the process)
+    nxt = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        np.testing.assert_array_equal(codes_after_step(nxt), want)
+        t2, dc2 = nxt.to_device(triples), nxt.to_device(dcodes)
+        nxt.capture_begin()
+        nxt.step_device(t2, E, dc2, train=True, seed=3)
+        gid = nxt.capture_end()
+        nxt.graph_launch(gid)
+        assert np.isfinite(nxt.codes()).all()
+        t2.free(); dc2.free()
+    finally:
+        nxt.close()
