@@ -7,7 +7,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 6 --warmup 2 --cpu-steps 0 --no-kernel-profile --no-extra-workloads --no-fp32-reference"
 export RGCN_STREAMS=0 RGCN_BENCH_PREFETCH=0
-pass() { n=$1; shift; timeout 120 rocprofv3 --pmc "$@" -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1; for k in k_block_msg_fwd k_block_msg_bwd k_combine; do python tools/pmc_summary.py $OUT/$n/${n}_results.db $k; done; }
+pass() { n=$1; shift; timeout 60 rocprofv3 --pmc "$@" -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1; for k in k_block_msg_fwd k_block_msg_bwd k_combine; do python tools/pmc_summary.py $OUT/$n/${n}_results.db $k; done; }
 pass p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
 pass p2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES
 # (a TA_* pass aborted rocprofv3 with signal 6 and hung the visit for its whole limit on this image: left out)
