@@ -19,7 +19,9 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                   shapes (configs 4 and 5 on one GPU), the 38,001-edge and the 272,115-edge full graphs,
   "train_steps":  (same run) whole training iterations on the device at the FB15k-237 and FB15k sizes: the minibatch
                   step train.py launches (edge dropout + negatives + prep + encoder + DistMult + clip + Adam) and
-                  configs[4]'s hipGraph-captured train step, replayed against stream-launched.
+                  configs[4]'s hipGraph-captured train step, replayed against stream-launched,
+  "evaluation":   (same run) the reference's evaluation pass: test-mode encoding of the 272,115-edge graph, raw + filtered
+                  ranks of 2,000 triples on both sides against all entities.
 """
 from __future__ import annotations
 
@@ -560,6 +562,61 @@ def measure_train_step(name, args, steps, warmup):
     return out
 
 
+def measure_evaluation(args, queries=2000):
+    """The evaluation half of the reference's loop ("next" row f3 of SURVEY 8; code/common/evaluation.py:148-153,349-389,
+    model.py:59-81): one test-mode encoding of the full training graph (272,115 edges, SURVEY 8d graph B) and raw +
+    filtered ranks of `queries` test triples on both sides (subject and object), filter lists from the graph itself."""
+    import numpy as np
+    from relationprediction_amd import _native
+    from relationprediction_amd.common.shared_functions import init_encoder_params
+    graph_name, V, R, d, L, kind, nb, E = WORKLOADS["fb237_block_traingraph"]
+    triples = load_graph(graph_name)
+    q = np.ascontiguousarray(load_graph("fb237_valid_test")[:queries])
+    eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E)
+    out = {"workload": "fb237_block_evaluation", "graph_edges": E, "queries": int(len(q)), "entities": V}
+    try:
+        eng.set_gemm_mode(args.gemm_mode)
+        eng.set_params(init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1)))
+        tri_dev = eng.to_device(triples)
+        eng.set_graph_device(tri_dev, E)
+        eng.forward(train=False)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.set_graph_device(tri_dev, E)
+            eng.forward(train=False)
+        eng.sync()
+        out["encode_full_graph_ms"] = round((time.perf_counter() - t0) * 1e3 / 5, 3)
+        # filter lists (Scorer.known_*_triples): every completion of (entity, relation) seen in graph + queries
+        allt = np.concatenate([triples, q]).astype(np.int64)
+        eng.rank_reserve(1000)                                  # the reference scores chunks of 1000 triples
+        ranks_ms, mrr = 0.0, {}
+        for object_side in (True, False):
+            ent, other = (allt[:, 0], allt[:, 2]) if object_side else (allt[:, 2], allt[:, 0])
+            key = ent * R + allt[:, 1]
+            order = np.argsort(key, kind="stable")
+            ks, vs = key[order], other[order]
+            qkey = (q[:, 0].astype(np.int64) if object_side else q[:, 2].astype(np.int64)) * R + q[:, 1]
+            lo, hi = np.searchsorted(ks, qkey, "left"), np.searchsorted(ks, qkey, "right")
+            idx = np.concatenate([np.unique(vs[a:b]) for a, b in zip(lo, hi)]).astype(np.int32)
+            ptr = np.concatenate([[0], np.cumsum([len(np.unique(vs[a:b])) for a, b in zip(lo, hi)])]).astype(np.int64)
+            eng.sync()
+            t0 = time.perf_counter()
+            raw, filt = eng.ranks(q, object_side, ptr, idx)
+            ranks_ms += (time.perf_counter() - t0) * 1e3
+            mrr["object" if object_side else "subject"] = [round(float(np.mean(1.0 / raw)), 5),
+                                                           round(float(np.mean(1.0 / filt)), 5)]
+        out["rank_both_sides_ms"] = round(ranks_ms, 3)
+        out["ranked_triples_per_s"] = round(len(q) / (ranks_ms * 1e-3), 1)
+        out["mrr_raw_filtered_random_weights"] = mrr
+        out["note"] = ("ranks: host call to host call (uploads of the queries and filter lists and the download of the "
+                       "ranks included); scores of every query against all %d entities, chunks of 1000" % V)
+        tri_dev.free()
+    finally:
+        eng.close()
+    return out
+
+
 def main():
     args = parse_args()
     rk = Ranks(args)
@@ -578,9 +635,13 @@ def main():
     if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
         for w in TRAIN_STEP_WORKLOADS:
             train_steps.append(measure_train_step(w, args, args.extra_steps, min(args.warmup, 5)))
+    evaluation = None
+    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
+        evaluation = measure_evaluation(args)
     if rk.rank == 0:
         out["workloads"] = extras
         out["train_steps"] = train_steps
+        out["evaluation"] = evaluation
     if rk.world > 1 and rk.rank == 0 and os.path.exists(rk.rdv_path):
         os.remove(rk.rdv_path)
 

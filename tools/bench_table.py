@@ -20,6 +20,10 @@ for t in d.get("train_steps", []):
     print("%-24s minibatch step %7.3f ms (%.2f M edges/s, %.0f M triples/s)   captured step: hipGraph replay %7.3f ms, streams %7.3f ms" % (
         t["workload"], m.get("ms_per_step", 0), m.get("edges_per_s", 0) / 1e6, m.get("triples_per_s", 0) / 1e6,
         c.get("ms_per_step_hipgraph_replay", 0), c.get("ms_per_step_stream_launched", 0)))
+if d.get("evaluation"):
+    e = d["evaluation"]
+    print("evaluation: encode %d-edge graph %.3f ms; ranks of %d triples, both sides: %.1f ms (%.0f triples/s)" % (
+        e["graph_edges"], e["encode_full_graph_ms"], e["queries"], e["rank_both_sides_ms"], e["ranked_triples_per_s"]))
 print("cpu", d.get("cpu_baseline"))
 print("fp32 mfma reference", d.get("fp32_mfma_reference"))
 for o in [d] + (d.get("workloads", []) if "-v" in sys.argv else []):
