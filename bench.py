@@ -404,7 +404,14 @@ def measure(workload, args, rk, steps, warmup, full):
             oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)
             ts.append(time.perf_counter() - c0)
         med = float(np.median(ts))
-        cpu = {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+        model_name = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                model_name = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+        except OSError:
+            pass
+        cpu = {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "cpu_model": model_name,
+               "kind": "port",
                "ms_per_step": round(med * 1e3, 1),
                "threads": "BLAS threads = host cores for the dense products (self-loop, basis); the sparse incidence "
                           "products, gathers and batched 5x5 products of the TF-shaped dataflow run on one thread",
