@@ -284,13 +284,18 @@ __device__ __forceinline__ void ent_range(const EntArgs& a, int s0, int s1, int 
   }
 }
 
+// kEntThreads = 256 (was 1024): the workgroups are scheduled in finer grain (k_combine gained 10-13 % that way,
+// elementwise.hip).  A piece of a long row is still summed over EIGHT interleaved slot lanes whose partial sums are
+// added in lane order; 256 threads carry them as 2 physical x 4 virtual lanes -- the same arithmetic as before.
+constexpr int kEntThreads = 256;
 template <int VEC, int TPR>
-__global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int n_long_blocks) {
+__global__ void __launch_bounds__(kEntThreads) k_dec_entity_grad(EntArgs a, int n_long_blocks) {
   const int nvec = a.d / VEC;
+  constexpr int NSL = kEntThreads / 128, VL = 8 / NSL;
   if ((int)blockIdx.x < n_long_blocks) {
-    __shared__ float red[8][128 * VEC];
+    __shared__ float red[(NSL - 1) * VL][128 * VEC];
     const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    // one PIECE of a long row per turn: 8 slot lanes x 128 column lanes, partial sum to the piece slab
+    // one PIECE of a long row per turn, partial sum to the piece slab
     const int n = a.nlong[1];
     for (int lb = blockIdx.x; lb < n; lb += n_long_blocks) {
       const int v = a.piece_row[lb];
@@ -298,19 +303,29 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int 
       const int end = min(a.row_ptr[v + 1], beg + kDecPiece);
       for (int c0 = 0; c0 < nvec; c0 += 128) {
         const int cidx = c0 + cl;
-        float acc[VEC];
+        float part[VL][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        if (cidx < nvec) ent_range<VEC>(a, beg + sl, end, 8, cidx, acc);
+        for (int j = 0; j < VL; ++j) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
+          for (int k = 0; k < VEC; ++k) part[j][k] = 0.f;
+          if (cidx < nvec) ent_range<VEC>(a, beg + sl * VL + j, end, 8, cidx, part[j]);
+        }
+        if (sl > 0) {
+#pragma unroll
+          for (int j = 0; j < VL; ++j)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red[(sl - 1) * VL + j][cl * VEC + k] = part[j][k];
+        }
         __syncthreads();
         if (sl == 0 && cidx < nvec) {
+          float acc[VEC];
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
-            float t = red[0][cl * VEC + k];
+            float t = part[0][k];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) t += red[w][cl * VEC + k];
+            for (int j = 1; j < VL; ++j) t += part[j][k];
+#pragma unroll
+            for (int w = 0; w < (NSL - 1) * VL; ++w) t += red[w][cl * VEC + k];
             acc[k] = t;
           }
           vstore<VEC>(a.piece_slab + (size_t)lb * a.d + (size_t)cidx * VEC, acc);
@@ -320,7 +335,7 @@ __global__ void __launch_bounds__(kRowThreads) k_dec_entity_grad(EntArgs a, int 
     }
     return;
   }
-  const int v = ((int)blockIdx.x - n_long_blocks) * (kRowThreads / TPR) + threadIdx.x / TPR;
+  const int v = ((int)blockIdx.x - n_long_blocks) * (kEntThreads / TPR) + threadIdx.x / TPR;
   if (v >= a.V) return;
   const int lane = threadIdx.x % TPR;
   const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
@@ -710,10 +725,11 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     a.k = k;
     const int nvec = vec4 ? d / 4 : d;
     const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-    const int rpb = kRowThreads / tpr;
+    const int rpb = kEntThreads / tpr;
     int64_t want = 2 * (int64_t)N / 2048;
-    const int nlb = (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
-    dim3 grid(nlb + (V + rpb - 1) / rpb), block(kRowThreads);
+    // (sized for 1024-thread workgroups; four times as many of the 256-thread ones walk the long-row pieces)
+    const int nlb = 4 * (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
+    dim3 grid(nlb + (V + rpb - 1) / rpb), block(kEntThreads);
     ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d);
 #define RGCN_LAUNCH_EG(VEC, TPR) hipLaunchKernelGGL((k_dec_entity_grad<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
     if (vec4) {

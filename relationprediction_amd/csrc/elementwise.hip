@@ -88,93 +88,107 @@ __device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, si
   }
 }
 
-constexpr int kCombineThreads = 1024;
+constexpr int kCombineThreads = 256;
 constexpr int kLongBlocksMin = 64;  // extra workgroups of the combine grid that walk the long-row list
 
-// Workgroups [0, nb_rows): TPR lanes per row, 1024 / TPR rows per workgroup, rows with more than
-// kLongRow slots are skipped.  Workgroups [nb_rows, nb_rows + kLongBlocks): one LONG row at a time
-// with 1024 / 128 = 8 slot-lanes x 128 column lanes (16 loads in flight per lane), LDS combines the
-// 8 partial sums in a fixed order -- a hub never serialises one wave group, and no extra launch.
+// Sum of the slots [beg, end) of one row at column vector cidx, by the whole workgroup: EIGHT interleaved slot lanes
+// (lane q adds the slots beg + q, beg + q + 8, ... in increasing order), THREADS / 128 of them physical
+// (threadIdx.x >> 7), each carrying VL = 8 / (THREADS / 128) virtual ones side by side (16 loads in flight per thread
+// either way); the eight partial sums are then added in lane order ((0 + 1) + 2) ... -- the same arithmetic whatever
+// THREADS is, and the one the GEMM's fused epilogue uses.  The result is valid in the threads with sl == 0 (and
+// cidx < nvec).  red: [(THREADS / 128 - 1) * VL][128 * VEC] floats of LDS.
+template <int VEC, int THREADS>
+__device__ __forceinline__ void sum_long_row(const float* __restrict__ msg, int d, int nvec, int cidx, int beg, int end,
+                                             float* __restrict__ red, float (&tot)[VEC]) {
+  constexpr int NSL = THREADS / 128, VL = 8 / NSL, UNR = 16 / VL;
+  const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  float part[VL][VEC];
+#pragma unroll
+  for (int j = 0; j < VL; ++j)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) part[j][k] = 0.0f;
+  if (cidx < nvec) {
+    const float* mp = msg + (size_t)cidx * VEC;
+    for (int s0 = beg + sl * VL; s0 < end; s0 += 8 * UNR) {      // slot of virtual lane 0, round by round
+      float m[UNR][VL][VEC];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+          const int sidx = s0 + j + 8 * u;
+          if (sidx < end) vload<VEC>(mp + (size_t)sidx * d, m[u][j]);
+          else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) m[u][j][k] = 0.0f;
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int j = 0; j < VL; ++j)
+          if (s0 + j + 8 * u < end) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) part[j][k] += m[u][j][k];
+          }
+    }
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int j = 0; j < VL; ++j)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) red[((size_t)((sl - 1) * VL + j) * 128 + cl) * VEC + k] = part[j][k];
+  }
+  __syncthreads();
+  if (sl == 0) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float t = part[0][k];
+#pragma unroll
+      for (int j = 1; j < VL; ++j) t += part[j][k];
+#pragma unroll
+      for (int q = 0; q < (NSL - 1) * VL; ++q) t += red[((size_t)q * 128 + cl) * VEC + k];
+      tot[k] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// Workgroups [0, n_long_blocks): one LONG row (more than kLongRow slots) at a time, summed by the whole workgroup
+// (sum_long_row); they come FIRST in the grid so that they start at t = 0 and finish under the cover of the ordinary
+// rows -- a hub never serialises one wave group, and no extra launch.  Workgroups behind them: TPR lanes per row,
+// THREADS / TPR rows per workgroup, long rows skipped.
+// 256-thread workgroups: measured 27 / 31 us forward / backward against 31 / 36-38 with 1024 (finer scheduling grain;
+// and a 256-thread workgroup with 8 KB of LDS finds room on a CU that two GEMM workgroups occupy, where a 1024-thread
+// one needs the CU to itself).  Round 2 also had the column sums of the last backward combine (db_emb) gathered in
+// this kernel, one partial row per 1024-thread workgroup: that launch took ~42 us against 31 + 7 for the small
+// workgroups and a separate column-sum pass, and is gone.
 template <int VEC, int TPR>
 __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int n_long_blocks) {
+  constexpr int THREADS = kCombineThreads;
   const int nvec = a.d / VEC;
-  // [8 slot lanes][128 column lanes] partial sums of the long rows / [rows][TPR lanes] values of the ordinary rows
-  // for the fused column sums
-  __shared__ float shm[kCombineThreads * VEC];
-  // the long-row workgroups come FIRST in the grid so that they start at t = 0 and finish under the
-  // cover of the ordinary rows
+  constexpr int NSL = THREADS / 128, VL = 8 / NSL;
+  __shared__ float shm[(NSL - 1) * VL * 128 * VEC];       // partial sums of the long rows' slot lanes
   if ((int)blockIdx.x < n_long_blocks) {
-    float (*red)[128 * VEC] = reinterpret_cast<float (*)[128 * VEC]>(shm);
     const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    // column sums of `out` over the rows this workgroup finishes (a.colsum_part: nvec <= 128, one column chunk)
-    float cs[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) cs[k] = 0.0f;
-    if (a.msg == nullptr) {
-      if (a.colsum_part != nullptr && sl == 0 && cl < nvec)
-        vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cl * VEC, cs);
-      return;
-    }
+    if (a.msg == nullptr) return;
     const int n = *a.nlong;
     for (int b = blockIdx.x; b < n; b += n_long_blocks) {
       const int v = a.long_rows[b];
       const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
       for (int c0 = 0; c0 < nvec; c0 += 128) {
         const int cidx = c0 + cl;
-        float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-        if (cidx < nvec) {
-          const float* mp = a.msg + (size_t)cidx * VEC;
-          int s = beg + sl;
-          for (; s + 8 * 15 < end; s += 8 * 16) {
-            float m[16][VEC];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * a.d, m[u]);
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-              for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
-          }
-          for (; s + 24 < end; s += 32) {
-            float m0[VEC], m1[VEC], m2[VEC], m3[VEC];
-            vload<VEC>(mp + (size_t)(s + 0) * a.d, m0);
-            vload<VEC>(mp + (size_t)(s + 8) * a.d, m1);
-            vload<VEC>(mp + (size_t)(s + 16) * a.d, m2);
-            vload<VEC>(mp + (size_t)(s + 24) * a.d, m3);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = (((acc[k] + m0[k]) + m1[k]) + m2[k]) + m3[k];
-          }
-          for (; s < end; s += 8) {
-            float m0[VEC];
-            vload<VEC>(mp + (size_t)s * a.d, m0);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
-        __syncthreads();
+        float sum[VEC];
+        sum_long_row<VEC, THREADS>(a.msg, a.d, nvec, cidx, beg, end, shm, sum);
         if (sl == 0 && cidx < nvec) {
           const size_t off = (size_t)v * a.d + (size_t)cidx * VEC;
           float tot[VEC];
           combine_prologue<VEC>(a, v, off, tot);
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            float t = red[0][cl * VEC + k];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
-            tot[k] += t;
-          }
+          for (int k = 0; k < VEC; ++k) tot[k] += sum[k];
           combine_epilogue<VEC>(a, off, tot);
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) cs[k] += tot[k];
         }
-        __syncthreads();
       }
     }
-    if (a.colsum_part != nullptr && sl == 0 && cl < nvec)
-      vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cl * VEC, cs);
     // giant rows (full-graph scale): one kGiantRow-slot PIECE per turn, partial sum to the piece slab; the
     // finishing kernel adds the pieces of a row in order and applies prologue / epilogue
     if (a.ngiant != nullptr) {
@@ -185,49 +199,15 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
         const int end = min(a.row_ptr[v + 1], beg + kGiantRow);
         for (int c0 = 0; c0 < nvec; c0 += 128) {
           const int cidx = c0 + cl;
-          float acc[VEC];
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-          if (cidx < nvec) {
-            const float* mp = a.msg + (size_t)cidx * VEC;
-            int s = beg + sl;
-            for (; s + 8 * 15 < end; s += 8 * 16) {
-              float m[16][VEC];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) vload<VEC>(mp + (size_t)(s + 8 * u) * a.d, m[u]);
-#pragma unroll
-              for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
-            }
-            for (; s < end; s += 8) {
-              float m0[VEC];
-              vload<VEC>(mp + (size_t)s * a.d, m0);
-#pragma unroll
-              for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) red[sl][cl * VEC + k] = acc[k];
-          __syncthreads();
-          if (sl == 0 && cidx < nvec) {
-            float tot[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-              float t = red[0][cl * VEC + k];
-#pragma unroll
-              for (int q = 1; q < 8; ++q) t += red[q][cl * VEC + k];
-              tot[k] = t;
-            }
-            vstore<VEC>(a.giant_slab + (size_t)b * a.d + (size_t)cidx * VEC, tot);
-          }
-          __syncthreads();
+          float tot[VEC];
+          sum_long_row<VEC, THREADS>(a.msg, a.d, nvec, cidx, beg, end, shm, tot);
+          if (sl == 0 && cidx < nvec) vstore<VEC>(a.giant_slab + (size_t)b * a.d + (size_t)cidx * VEC, tot);
         }
       }
     }
     return;
   }
-  const int rows_per_block = kCombineThreads / TPR;
+  const int rows_per_block = THREADS / TPR;
   const int local = ((int)blockIdx.x - n_long_blocks) * rows_per_block + threadIdx.x / TPR;
   const int v = a.v_begin + local;
   const int lane = threadIdx.x % TPR;
@@ -238,8 +218,8 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
     end = a.row_ptr[v + 1];
     if (end - beg > kLongRow) active = false;       // handled by a long-row workgroup of this same launch
   }
-  if (a.colsum_part == nullptr && !active) return;
-  for (int c0 = 0; c0 < nvec; c0 += TPR) {            // one turn whenever the column sums are fused (nvec <= TPR)
+  if (!active) return;
+  for (int c0 = 0; c0 < nvec; c0 += TPR) {
     const int cidx = c0 + lane;
     float acc[VEC];
 #pragma unroll
@@ -265,23 +245,6 @@ __global__ void __launch_bounds__(kCombineThreads) k_combine(CombineArgs a, int 
         for (int k = 0; k < VEC; ++k) acc[k] += m0[k];
       }
       combine_epilogue<VEC>(a, off, acc);             // acc = what went to `out`
-    }
-    if (a.colsum_part != nullptr) {
-      // db_emb (column sums of dW_emb = `out` of the last backward combine) without another pass over [V,d]:
-      // the workgroup's rows are added in row order, one partial row per workgroup, k_colsum_final adds those
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) shm[threadIdx.x * VEC + k] = acc[k];
-      __syncthreads();
-      if (threadIdx.x < TPR && cidx < nvec) {
-        float t[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) t[k] = 0.0f;
-        for (int r = 0; r < rows_per_block; ++r)
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) t[k] += shm[(r * TPR + lane) * VEC + k];
-        vstore<VEC>(a.colsum_part + (size_t)blockIdx.x * a.d + (size_t)cidx * VEC, t);
-      }
-      __syncthreads();
     }
   }
 }
@@ -363,24 +326,46 @@ __global__ void k_materialize_mask(uint8_t* out, int64_t n, DropSpec ds) {
 // 8 independent row loads in flight, the 4 row lanes combine through LDS -> part[by][col].
 // stage 2: 64 column lanes x 16 part lanes per block sum the partials in a fixed order.
 constexpr int kColRowsPerBlock = 32;
+// stage 1: block by: rows [by * 32, by * 32 + 32); 128 column lanes (VEC columns each) x 2 row lanes; every thread adds its
+// 16 rows 8 at a time (8 independent 16-byte loads in flight), the two row lanes meet in LDS -> part[by][cols].
+template <int VEC>
 __global__ void __launch_bounds__(256) k_colsum_part(const float* __restrict__ in, float* __restrict__ part,
                                                     int rows, int cols) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  const int r0 = blockIdx.y * kColRowsPerBlock + rl * 8;
-  float acc = 0.f;
+  __shared__ float red[128 * VEC];
+  const int cl = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int col = (blockIdx.x * 128 + cl) * VEC;
+  const int r0 = blockIdx.y * kColRowsPerBlock + rl;          // rows r0, r0 + 2, ...
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
   if (col < cols) {
-    float m[8];
+    for (int r = r0; r < min(rows, (int)(blockIdx.y + 1) * kColRowsPerBlock); r += 16) {
+      float m[8][VEC];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) m[u] = (r0 + u < rows) ? in[(size_t)(r0 + u) * cols + col] : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        if (r + 2 * u < rows && r + 2 * u < (int)(blockIdx.y + 1) * kColRowsPerBlock)
+          vload<VEC>(in + (size_t)(r + 2 * u) * cols + col, m[u]);
+        else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += m[u];
+          for (int k = 0; k < VEC; ++k) m[u][k] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += m[u][k];
+    }
   }
-  red[rl][cl] = acc;
+  if (rl == 1) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[cl * VEC + k] = acc[k];
+  }
   __syncthreads();
-  if (rl == 0 && col < cols)
-    part[(size_t)blockIdx.y * cols + col] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+  if (rl == 0 && col < cols) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += red[cl * VEC + k];
+    vstore<VEC>(part + (size_t)blockIdx.y * cols + col, acc);
+  }
 }
 __global__ void __launch_bounds__(1024) k_colsum_final(const float* __restrict__ part, float* __restrict__ out,
                                                       int nparts, int cols) {
@@ -450,24 +435,17 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a_in, doubl
                     aligned16(a.gate) && aligned16(a.out2);
   const int nvec = vec4 ? a.d / 4 : a.d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-  const int rows_per_block = kCombineThreads / tpr;
   const int nrows = a.v_count < 0 ? a.V : a.v_count;
-  const int nb_rows = (nrows + rows_per_block - 1) / rows_per_block;
   // enough long-row workgroups for the graph at hand: one per ~1024 slots, at least 64, at most 1024
   int n_long_blocks = 0;
   if (a.msg != nullptr) {
     int64_t want = 2 * c->g.E / 1024;
     n_long_blocks = (int)(want < kLongBlocksMin ? kLongBlocksMin : (want > 1024 ? 1024 : want));
   }
+  n_long_blocks *= 4;       // (sized for 1024-thread workgroups: the same number of threads on the long rows)
+  const int rows_per_block = kCombineThreads / tpr;
+  const int nb_rows = (nrows + rows_per_block - 1) / rows_per_block;
   dim3 grid(nb_rows + n_long_blocks), block(kCombineThreads);
-  c->colsum_parts = 0;
-  if (a.colsum_part != nullptr) {
-    // fused column sums: one column chunk per row (nvec <= 128), no giant rows, room for one partial row per workgroup
-    if (vec4 && nvec <= 128 && !giant && 2 * c->g.E <= 65536 &&
-        ((size_t)grid.x + grid.x / kColRowsPerBlock + 2) * a.d <= c->colsum_part_floats)
-      c->colsum_parts = (int)grid.x;
-    else a.colsum_part = nullptr;
-  }
   ProfScope ps(c, tag, alg_bytes, 0);
 #define RGCN_LAUNCH_COMBINE(VEC, TPR) \
   hipLaunchKernelGGL((k_combine<VEC, TPR>), grid, block, 0, c->stream, a, n_long_blocks)
@@ -529,16 +507,15 @@ rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, 
 
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols) {
   float* part = c->colsum_part;
-  if (c->colsum_parts > 0) {      // the last combine left per-workgroup partial rows of exactly these sums: add THOSE
-    in = c->colsum_part;
-    rows = c->colsum_parts;
-    part = c->colsum_part + (size_t)rows * cols;      // second-level partials behind them
-    c->colsum_parts = 0;
-  }
   const int nparts = (rows + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  if ((size_t)nparts * cols > c->colsum_part_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: column-sum scratch too small");
   ProfScope ps(c, "bias_grad_colsum", 4.0 * rows * cols, 0);
-  hipLaunchKernelGGL(k_colsum_part, dim3((cols + 63) / 64, nparts), dim3(256), 0, c->stream, in,
-                     part, rows, cols);
+  if (cols % 4 == 0 && aligned16(in))
+    hipLaunchKernelGGL((k_colsum_part<4>), dim3((cols / 4 + 127) / 128, nparts), dim3(256), 0, c->stream, in, part, rows,
+                       cols);
+  else
+    hipLaunchKernelGGL((k_colsum_part<1>), dim3((cols + 127) / 128, nparts), dim3(256), 0, c->stream, in, part, rows,
+                       cols);
   hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(1024), 0, c->stream,
                      part, out, nparts, cols);
   RGCN_HIP(c, hipGetLastError());

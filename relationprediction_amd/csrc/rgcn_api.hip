@@ -632,7 +632,6 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
     a.out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
-    if (l - 1 == 0) a.colsum_part = c->colsum_part;      // db_emb = column sums of dW_emb, gathered on the way
     a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
     a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
     a.gate = Hin;

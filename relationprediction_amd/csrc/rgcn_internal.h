@@ -273,7 +273,6 @@ struct rgcn_ctx {
   uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
   float* colsum_part = nullptr;
   size_t colsum_part_floats = 0;
-  int colsum_parts = 0;                  // partial rows the last combine left in colsum_part (0: none)
   float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
 
   rgcn::GraphBufs g;                     // ACTIVE graph structures
@@ -423,7 +422,6 @@ struct CombineArgs {
   int32_t v_begin = 0, v_count = -1;   // rows the launch walks: [v_begin, v_begin + v_count) (v_count < 0: all V)
   DropSpec drop;         // applied to base
   DropSpec drop2;        // applied to out2
-  float* colsum_part = nullptr;   // optional: per-workgroup column sums of `out` (one row of d floats per workgroup)
 };
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
 rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
