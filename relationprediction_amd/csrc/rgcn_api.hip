@@ -541,7 +541,12 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     // the stream of the kernel that finishes LAST: schedule 1 keeps the messages on the main stream and
     // forks the (shorter) GEMM; schedule 0 is the reverse.
     static const int fsched = getenv("RGCN_FWD_SCHED") ? atoi(getenv("RGCN_FWD_SCHED")) : 1;
-    if (fsched == 1) {
+    if (fsched == 2) {      // everything on the main stream, no fork and no join
+      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+      RGCN_TRY(wait_gather(c));
+      RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    } else if (fsched == 1) {
       {   // self-loop: S = H . W_self  (rows of this rank's shard)
         StreamScope side(c, 0);
         RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
@@ -558,7 +563,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
                         c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     }
-    RGCN_TRY(stream_join(c, 0));
+    if (fsched != 2) RGCN_TRY(stream_join(c, 0));
     CombineArgs a;
     a.add = nullptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
