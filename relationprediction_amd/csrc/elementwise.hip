@@ -157,7 +157,8 @@ __device__ __forceinline__ void sum_long_row(const float* __restrict__ msg, int 
 // (sum_long_row); they come FIRST in the grid so that they start at t = 0 and finish under the cover of the ordinary
 // rows -- a hub never serialises one wave group, and no extra launch.  Workgroups behind them: TPR lanes per row,
 // THREADS / TPR rows per workgroup, long rows skipped.
-// 256-thread workgroups: measured 27 / 31 us forward / backward against 31 / 36-38 with 1024 (finer scheduling grain;
+// 256-thread workgroups: measured (forward / backward launch, us) 128: 33.9 / 38.0, 256: 27.4 / 33.0, 512: 29.7 / 35.5,
+// 1024: 31 / 36-38 (finer scheduling grain;
 // and a 256-thread workgroup with 8 KB of LDS finds room on a CU that two GEMM workgroups occupy, where a 1024-thread
 // one needs the CU to itself).  Round 2 also had the column sums of the last backward combine (db_emb) gathered in
 // this kernel, one partial row per 1024-thread workgroup: that launch took ~42 us against 31 + 7 for the small
