@@ -54,3 +54,32 @@ def test_bench_multi_rank_prints_one_json_line_last(collective, world):
     names = {k["kernel"] for k in out["kernels"]}
     assert out["roofline"] and {"rccl_allreduce", "rccl_reduce_scatter", "rccl_all_gather"} <= names
     assert out["comm_ms_per_step"] > 0
+
+
+def test_bench_single_gpu_line_carries_every_section():
+    """The driver's call with small counts: ONE JSON line (the last line of stdout) with the contract keys, the
+    roofline and cpu_baseline objects, the other BASELINE configurations ("workloads"), the device train steps
+    ("train_steps", config 5's captured step among them) and the evaluation pass ("evaluation")."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--extra-steps", "2",
+                        "--cpu-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["config"]["workload"] == "fb237_block" and d["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert [w["config"]["workload"] for w in d["workloads"]] == ["fb237_basis_b2", "fb237_basis_b5", "wn18_block",
+                                                                 "fb15k_block", "fb237_block_fullgraph",
+                                                                 "fb237_block_traingraph"]
+    assert all(w["ms_per_step"] > 0 and w["roofline"] for w in d["workloads"])
+    assert [t["workload"] for t in d["train_steps"]] == ["fb237_block_train_step", "fb15k_block_train_step"]
+    for t in d["train_steps"]:
+        assert t["minibatch_step"]["ms_per_step"] > 0 and t["minibatch_step"]["kernels"]
+        assert t["captured_step"]["ms_per_step_hipgraph_replay"] > 0 and t["captured_step"]["ms_per_step_stream_launched"] > 0
+    assert d["evaluation"]["ranked_triples_per_s"] > 0 and d["evaluation"]["encode_full_graph_ms"] > 0
