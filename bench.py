@@ -9,19 +9,25 @@ One "step" = one pass of the hot path over one minibatch graph already resident 
 device-side graph preparation of the fed [E,3] triples + 2-layer encoder forward (train mode, generated
 self-loop dropout) + backward for every encoder weight (rgcn_step_device).  value = E_g * steps / s.
 
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  "roofline":     the dominant kernel against its gfx950 roofline (live HIP-event durations),
-  "kernels":      the same accounting for every kernel of the step,
-  "cpu_baseline": the CPU oracle (TF-dataflow-shaped numpy/scipy port of the reference) timed on
-                  this box's host cores on the same minibatch,
-  "workloads":    (N = 1, default workload) the same measurement -- value, ms/step, roofline, kernels -- for the
-                  other BASELINE.json configurations on one GPU: basis B = 2 / B = 5 (config 3), the WN18 and FB15k
-                  shapes (configs 4 and 5 on one GPU), the 38,001-edge and the 272,115-edge full graphs,
+Rank 0 prints ONE COMPACT JSON line LAST on stdout (a few KB: tests hold it under 8 KB).  Besides the contract keys:
+  "roofline":     the dominant kernel against its gfx950 roofline (live HIP-event durations; fractions on COMPULSORY
+                  bytes / ALGORITHMIC flops, design and PMC bytes beside them),
+  "step_roofline": the whole step against the chip,
+  "cpu_baseline": the CPU oracle (TF-dataflow-shaped numpy/scipy port of the reference) timed on this box's host cores
+                  on the same minibatch; "cpu_baseline_reference_code": the reference's OWN model code over the numpy /
+                  torch shims, timed where /root/reference exists (the build container; committed, not re-measured here),
+  "top_kernels":  [name, launches/step, exclusive avg us, frac] of the six largest kernels,
+  "workloads":    (N = 1, default workload) one-line summaries -- value, ms/step, dominant kernel, frac, fraction of the
+                  serial ceiling -- of the other BASELINE.json configurations on one GPU: basis B = 2 / B = 5 (config 3), the
+                  WN18 and FB15k shapes (configs 4 and 5), the 38,001-edge and the 272,115-edge full graphs,
   "train_steps":  (same run) whole training iterations on the device at the FB15k-237 and FB15k sizes: the minibatch
-                  step train.py launches (edge dropout + negatives + prep + encoder + DistMult + clip + Adam) and
-                  configs[4]'s hipGraph-captured train step, replayed against stream-launched,
-  "evaluation":   (same run) the reference's evaluation pass: test-mode encoding of the 272,115-edge graph, raw + filtered
-                  ranks of 2,000 triples on both sides against all entities.
+                  step train.py launches and configs[4]'s hipGraph-captured train step, replayed against stream-launched,
+  "evaluation":   (same run) test-mode encoding of the 272,115-edge graph, raw + filtered ranks of 2,000 triples.
+Everything else -- the per-kernel tables of every workload and train step, notes -- goes to bench_details.json next to
+this file (and to gpurun_out/ when that directory exists), never to the result line.
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment spawns its own N ranks (one per GPU) and relays rank 0's
+line; under torch.distributed.run it is one of the ranks.
 """
 from __future__ import annotations
 
@@ -133,9 +139,7 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        if self.world != args.gpus:       # under a launcher the environment decides (main() self-spawns otherwise)
             args.gpus = self.world
         self.rdv_path = "/tmp/rgcn_rccl_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
 
@@ -165,36 +169,46 @@ def traffic_table(workload):
 
 
 def kernel_table(prof, steps, args, in_pipeline=None):
-    """rgcn_profile_get rows -> per-kernel accounting: exclusive average duration, algorithmic bytes / flops per launch
-    (what the launch site declares: DESIGN.md section 4), the roofline that bounds it and the achieved fraction."""
+    """rgcn_profile_get rows -> per-kernel accounting: exclusive average duration and, per launch, three byte counts --
+    compulsory (every distinct input byte once + every output byte once), design (what the launch site asks
+    of the memory system: gathers per use, staging slabs), pmc (filled in by the caller) -- and the algorithmic flops.
+    `frac` is computed on the COMPULSORY bytes (HBM-bound rows) or the ALGORITHMIC flops (MFMA-bound rows)."""
     in_pipeline = in_pipeline or {}
+    terms = args.gemm_mode if args.gemm_mode else 1
+    # roofline of an fp32 contraction in this arithmetic: every fp32 product costs `terms` bf16 MFMA products
+    mfma_peak = PEAK_BF16_MFMA_TFS / terms if args.gemm_mode else PEAK_F32_MFMA_TFS
     kernels = []
     for p in prof:
         if p["calls"] == 0:
             continue
         avg_ms = p["total_ms"] / p["calls"]
-        by, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
-        t_hbm = by / (PEAK_HBM_GBS * 1e9)
-        # flops the matrix cores execute: the split arithmetic issues `terms` bf16 MFMAs per fp32 product
-        terms = args.gemm_mode if args.gemm_mode else 1
-        mfma_peak = PEAK_BF16_MFMA_TFS if args.gemm_mode else PEAK_F32_MFMA_TFS
-        t_mfma = terms * fl / (mfma_peak * 1e12)
+        design, fl = p["alg_bytes"] / p["calls"], p["alg_flops"] / p["calls"]
+        comp = p.get("compulsory_bytes", p["alg_bytes"]) / p["calls"]
+        t_hbm = comp / (PEAK_HBM_GBS * 1e9)
+        t_mfma = fl / (mfma_peak * 1e12)
         bound = "mfma" if t_mfma > t_hbm else "hbm"
         sec = max(avg_ms, 1e-9) * 1e-3
         if bound == "mfma":
-            ach, peak, unit = terms * fl / sec / 1e12, mfma_peak, "TFLOP/s"
+            ach, peak, unit = fl / sec / 1e12, mfma_peak, "TFLOP/s"
         else:
-            ach, peak, unit = by / sec / 1e9, PEAK_HBM_GBS, "GB/s"
-        kernels.append({"kernel": p["name"], "launches_per_step": p["calls"] / steps,
-                        "avg_us": round(avg_ms * 1e3, 2),
-                        "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
-                        "ms_per_step": round(p["total_ms"] / steps, 4),
-                        "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "alg_bytes": by, "alg_flops": fl})
+            ach, peak, unit = comp / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+        k = {"kernel": p["name"], "launches_per_step": p["calls"] / steps,
+             "avg_us": round(avg_ms * 1e3, 2),
+             "avg_us_in_pipeline": round(in_pipeline.get(p["name"], 0.0) * 1e3, 2),
+             "ms_per_step": round(p["total_ms"] / steps, 4),
+             "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
+             "frac": round(ach / peak, 4), "compulsory_bytes": comp, "design_bytes": design, "alg_flops": fl,
+             "design_gbs": round(design / sec / 1e9, 1), "traffic": None}
         if bound == "mfma":
-            kernels[-1]["mfma_dtype"] = "bf16 (x%d exact operand split of fp32)" % terms if args.gemm_mode else "f32"
-            kernels[-1]["executed_flops"] = terms * fl
-            kernels[-1]["fp32_equivalent_tflops"] = round(fl / sec / 1e12, 2)
+            if args.gemm_mode:
+                k["peak_is"] = ("bf16 MFMA dense peak %.0f TF / %d partial products per fp32 product (exact 3-way bf16 "
+                                "operand split, fp32 accumulate)" % (PEAK_BF16_MFMA_TFS, terms))
+                k["frac_of_fp32_mfma_peak"] = round(fl / sec / 1e12 / PEAK_F32_MFMA_TFS, 4)
+                k["frac_of_bf16_peak_on_alg_flops"] = round(fl / sec / 1e12 / PEAK_BF16_MFMA_TFS, 4)
+                k["executed_bf16_tflops"] = round(terms * fl / sec / 1e12, 1)
+            else:
+                k["peak_is"] = "fp32 MFMA dense peak"
+        kernels.append(k)
     return kernels
 
 
@@ -353,14 +367,17 @@ def measure(workload, args, rk, steps, warmup, full):
             roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                         "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "traffic_source": traffic_src,
                         "avg_us": k["avg_us"], "avg_us_in_pipeline": k["avg_us_in_pipeline"],
-                        "note": "exclusive duration (overlap off); in the pipelined step it co-runs with HBM-bound kernels",
-                        "alg_per_launch": k["alg_flops"] if k["bound"] == "mfma" else k["alg_bytes"]}
-            for extra in ("mfma_dtype", "executed_flops", "fp32_equivalent_tflops"):
+                        "launches_per_step": k["launches_per_step"],
+                        "compulsory_bytes": k["compulsory_bytes"], "design_bytes": k["design_bytes"],
+                        "alg_flops": k["alg_flops"],
+                        "basis": "frac = algorithmic flops (MFMA) or compulsory bytes (HBM) per launch / exclusive "
+                                 "HIP-event duration / peak"}
+            for extra in ("peak_is", "frac_of_fp32_mfma_peak", "frac_of_bf16_peak_on_alg_flops", "executed_bf16_tflops"):
                 if extra in k:
                     roofline[extra] = k[extra]
 
     # ---- the whole step against the chip (north_star: throughput "as achieved fraction of HBM roofline"):
-    # algorithmic bytes / flops of every kernel of one step (this rank's share) over the measured step time
+    # compulsory / design / PMC bytes and algorithmic flops of one step (this rank's share) over the measured step time
     step_roofline = None
     if kernels:
         P, I = 4.0 * V * d, 12.0 * E_g
@@ -370,24 +387,27 @@ def measure(workload, args, rk, steps, warmup, full):
         else:
             Wl = 4.0 * (2 * d * nb * d + 2 * R * nb + d * d)
         compulsory = L * (2 * I + 5 * P + 3 * Wl) + 4 * P          # B_alg of one encoder step
-        staged = sum(k["alg_bytes"] * k["launches_per_step"] for k in kernels)
+        staged = sum(k["design_bytes"] * k["launches_per_step"] for k in kernels)
+        missing = [k["kernel"] for k in kernels if k["traffic"] is None and not k["kernel"].startswith("rccl_")
+                   and k["ms_per_step"] >= 0.002]
         measured = sum(k["traffic"] * k["launches_per_step"] for k in kernels if k["traffic"])
         sf = sum(k["alg_flops"] * k["launches_per_step"] for k in kernels)
         sec = ms_per_step * 1e-3
         ceiling = compulsory / (PEAK_HBM_GBS * 1e9) + sf / (PEAK_F32_MFMA_TFS * 1e12)
-        step_roofline = {"compulsory_bytes_per_step": compulsory, "kernel_sum_bytes_per_step": staged,
-                         "pmc_bytes_per_step": measured or None,
+        step_roofline = {"compulsory_bytes_per_step": compulsory, "design_bytes_per_step": staged,
+                         "pmc_bytes_per_step": measured or None, "pmc_missing_kernels": missing,
                          "alg_flops_per_step": sf,
                          "hbm_gbs": round(compulsory / sec / 1e9, 1),
                          "hbm_frac": round(compulsory / sec / 1e9 / PEAK_HBM_GBS, 4),
-                         "hbm_frac_kernel_sum": round(staged / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         "hbm_frac_design": round(staged / sec / 1e9 / PEAK_HBM_GBS, 4),
                          "fp32_tflops": round(sf / sec / 1e12, 2),
                          "fp32_mfma_frac": round(sf / sec / 1e12 / PEAK_F32_MFMA_TFS, 4),
                          "serial_ceiling_ms": round(ceiling * 1e3, 4),
                          "frac_of_serial_ceiling": round(ceiling / sec, 4),
+                         "sum_exclusive_kernel_ms": round(sum(k["ms_per_step"] for k in kernels), 4),
                          "note": "whole step on this rank over the measured step time.  compulsory = SURVEY 8d's "
                                  "L*(2I+5P+3W)+4P (each distinct input read once, each output written once); "
-                                 "kernel_sum = what the kernels move by design (messages staged through "
+                                 "design = what the kernels move by construction (messages staged through "
                                  "HBM / L2 between the relation-major and the row-major stage); pmc = rocprofv3 "
                                  "FETCH/WRITE_SIZE bytes of the committed PMC passes x launches; ceiling = "
                                  "compulsory / 8 TB/s + fp32 flops / 157.3 TF with nothing overlapped"}
@@ -437,6 +457,7 @@ def measure(workload, args, rk, steps, warmup, full):
             "data": data + "reference-distribution random-init weights, synthetic upstream gradient",
             "config": {"workload": workload, "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
+                       "norm_mode": "intended (1/deg of the edge's own row; SURVEY H1, DESIGN section 10)",
                        "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
                                 "two alternating minibatches, next graph's prep pipelined on a side stream"
                                 + ("; replayed from a captured hipGraph (2 steps per launch)" if use_graph else ""))
@@ -556,7 +577,7 @@ def measure_train_step(name, args, steps, warmup):
             ks.sort(key=lambda k: -k["ms_per_step"])
             out["minibatch_step"]["kernels"] = [
                 {f: k[f] for f in ("kernel", "launches_per_step", "avg_us", "ms_per_step", "bound", "achieved", "unit",
-                                   "frac")} for k in ks]
+                                   "frac", "compulsory_bytes", "design_bytes", "design_gbs")} for k in ks]
         out["captured_step"] = {"ms_per_step_hipgraph_replay": round(wall_g * 1e3 / steps, 4),
                                 "ms_per_step_stream_launched": round(wall_s * 1e3 / steps, 4),
                                 "entry_point": "rgcn_train_step_device inside rgcn_capture_begin / _end",
@@ -624,31 +645,131 @@ def measure_evaluation(args, queries=2000):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU; plain
+    subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment -- the same
+    contract torch.distributed.run provides), relay rank 0's stdout (its LAST line is the result line), send the
+    other ranks' output to stderr, and exit non-zero if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RGCN_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.exit("bench.py --gpus %d: rank(s) failed: %s" % (n, ", ".join("rank %d rc %d" % b for b in bad)))
+
+
+def compact_line(out):
+    """The one line the driver parses: contract keys + roofline + cpu_baseline(s) + step_roofline + summaries.
+    Kept to a few KB (tests/test_gpu_multiprocess.py holds it under 8 KB); the tables live in bench_details.json."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "config")}
+    for k in ("gpu_event_ms_per_step", "comm_ms_per_step", "message_edges_per_s", "speedup_vs_cpu"):
+        if k in out:
+            line[k] = out[k]
+    rf = out.get("roofline")
+    line["roofline"] = ({k: v for k, v in rf.items() if k != "basis"} if rf else None)
+    sr = out.get("step_roofline")
+    line["step_roofline"] = ({k: sr[k] for k in ("compulsory_bytes_per_step", "design_bytes_per_step", "pmc_bytes_per_step",
+                                                  "alg_flops_per_step", "hbm_frac", "fp32_mfma_frac", "serial_ceiling_ms",
+                                                  "frac_of_serial_ceiling", "sum_exclusive_kernel_ms")} if sr else None)
+    cpu = out.get("cpu_baseline")
+    line["cpu_baseline"] = ({k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step")} if cpu else None)
+    if out.get("cpu_baseline_reference_code"):
+        line["cpu_baseline_reference_code"] = out["cpu_baseline_reference_code"]
+    if out.get("fp32_mfma_reference"):
+        line["fp32_mfma_reference_ms_per_step"] = out["fp32_mfma_reference"]["ms_per_step"]
+    line["top_kernels"] = [[k["kernel"], k["launches_per_step"], k["avg_us"], k["frac"]] for k in out.get("kernels", [])[:6]]
+    line["workloads"] = [
+        {"workload": w["config"]["workload"], "value": w["value"], "ms_per_step": w["ms_per_step"],
+         "kernel": (w.get("roofline") or {}).get("kernel"), "bound": (w.get("roofline") or {}).get("bound"),
+         "frac": (w.get("roofline") or {}).get("frac"), "traffic": (w.get("roofline") or {}).get("traffic"),
+         "ceil": (w.get("step_roofline") or {}).get("frac_of_serial_ceiling")} for w in out.get("workloads", [])]
+    line["train_steps"] = [
+        {"workload": t["workload"], "ms_per_step": t["minibatch_step"]["ms_per_step"],
+         "edges_per_s": t["minibatch_step"]["edges_per_s"],
+         "hipgraph_ms": t["captured_step"]["ms_per_step_hipgraph_replay"],
+         "stream_ms": t["captured_step"]["ms_per_step_stream_launched"],
+         "top": [[k["kernel"], k["avg_us"], k["frac"]] for k in t["minibatch_step"].get("kernels", [])[:3]]}
+        for t in out.get("train_steps", [])]
+    ev = out.get("evaluation")
+    line["evaluation"] = ({k: ev[k] for k in ("graph_edges", "queries", "encode_full_graph_ms", "rank_both_sides_ms",
+                                               "ranked_triples_per_s")} if ev else None)
+    line["details"] = out.get("details")
+    return line
+
+
+def reference_code_baseline():
+    """The reference's OWN model code (code/common/model_builder.py chain over tests/golden/tf_numpy_shim.py forward +
+    tests/golden/tf_torch_shim.py autograd) timed on BASELINE config 2's minibatch.  /root/reference does not exist on
+    the GPU box, so this is measured where it does (tests/golden/time_reference_code.py, in the build container) and
+    committed; reported with its own host description, never mixed into `cpu_baseline`."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_code_timing.json")) as f:
+            t = json.load(f)
+        return {k: t[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step", "host", "measured_in_this_run")}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def write_details(out):
+    """per-kernel tables of every workload / train step: a side file, not the result line"""
+    paths = [os.path.join(ROOT, "bench_details.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    return written
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     rk = Ranks(args)
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
         import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
 
     out = measure(args.workload, args, rk, args.steps, args.warmup, full=True)
     extras = []
-    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
+    widen = rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph
+    if widen:
         for w in EXTRA_WORKLOADS:
             o = measure(w, args, rk, args.extra_steps, min(args.warmup, 5), full=False)
             for drop in ("cpu_baseline", "fp32_mfma_reference", "higher_is_better", "vs_baseline"):
                 o.pop(drop, None)
             extras.append(o)
     train_steps = []
-    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
+    if widen:
         for w in TRAIN_STEP_WORKLOADS:
             train_steps.append(measure_train_step(w, args, args.extra_steps, min(args.warmup, 5)))
-    evaluation = None
-    if rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph:
-        evaluation = measure_evaluation(args)
+    evaluation = measure_evaluation(args) if widen else None
     if rk.rank == 0:
         out["workloads"] = extras
         out["train_steps"] = train_steps
         out["evaluation"] = evaluation
+        if rk.world == 1 and args.workload == "fb237_block":
+            out["cpu_baseline_reference_code"] = reference_code_baseline()
     if rk.world > 1 and rk.rank == 0 and os.path.exists(rk.rdv_path):
         os.remove(rk.rdv_path)
 
@@ -674,7 +795,8 @@ def main():
                 if os.path.exists(p):
                     os.remove(p)
     if rk.rank == 0:
-        print(json.dumps(out), flush=True)
+        out["details"] = write_details(out)
+        print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)
 
 
 if __name__ == "__main__":

@@ -294,8 +294,9 @@ rgcn_status rgcn_prefetch_graph_dropout_device(rgcn_ctx* ctx, const int32_t* bat
  * (rgcn_step_device, rgcn_train_step_device, rgcn_prefetch_graph_device, rgcn_set_graph_device + rgcn_forward +
  * rgcn_backward_device ...) is recorded into a hipGraph instead of being executed, side streams included;
  * rgcn_graph_launch replays it on the context's stream with one launch.  Shapes and device pointers are the
- * captured ones (static shapes: refresh the CONTENTS of the triple / batch buffers between launches); dropout
- * masks differ from replay to replay (a device counter offsets the captured seeds) and Adam's step count
+ * captured ones (static shapes: refresh the CONTENTS of the triple / batch buffers between launches); every random
+ * draw differs from replay to replay -- a device counter offsets the captured seeds: replay k of a graph draws the
+ * dropout masks, the edge-dropout subset and the negative samples of (captured seed + k) -- and Adam's step count
  * advances on the device.  Calls that synchronise or touch host memory return RGCN_ERR_STATE during a capture;
  * run one ordinary step first so that every lazily allocated buffer exists.  To keep the graph preparation of
  * the next minibatch overlapped inside a graph, capture an even number of steps, each followed by the prefetch
@@ -375,13 +376,17 @@ rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t on);
 rgcn_status rgcn_set_gemm_mode(rgcn_ctx* ctx, int32_t mode);
 
 /* Per-kernel profile: when enabled every launch is bracketed by HIP events on the context's stream.
- * Records aggregate by kernel name; alg_bytes / alg_flops are the ALGORITHMIC bytes / flops of the
- * launches ("roofline accounting"), summed over calls. */
+ * Records aggregate by kernel name, summed over calls.  alg_bytes = the DESIGN bytes of the launches (what the
+ * kernel asks of the memory system by construction: a gathered row counts once per use, staging slabs count);
+ * alg_flops = the algorithmic flops; rgcn_profile_get_compulsory = the COMPULSORY bytes (every distinct input byte
+ * once + every output byte once) -- the figure roofline fractions are computed on.
+ * The reference has no counterpart (TF's timeline is not used by code/train.py). */
 rgcn_status rgcn_profile_enable(rgcn_ctx* ctx, int32_t on);
 rgcn_status rgcn_profile_reset(rgcn_ctx* ctx);
 int32_t     rgcn_profile_count(rgcn_ctx* ctx); /* synchronises, aggregates; number of kernel names */
 rgcn_status rgcn_profile_get(rgcn_ctx* ctx, int32_t i, char* name, int32_t name_cap, int64_t* calls,
                              double* total_ms, double* alg_bytes, double* alg_flops);
+rgcn_status rgcn_profile_get_compulsory(rgcn_ctx* ctx, int32_t i, double* compulsory_bytes);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,7 @@ _SIGS = {
     "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_reset": (C.c_int32, [_P]),
     "rgcn_profile_count": (C.c_int32, [_P]),
+    "rgcn_profile_get_compulsory": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double)]),
     "rgcn_profile_get": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -617,7 +618,7 @@ class Engine:
         self._check(self.lib.rgcn_profile_reset(self.ctx))
 
     def profile(self):
-        """[{name, calls, total_ms, alg_bytes, alg_flops}] aggregated per kernel name."""
+        """[{name, calls, total_ms, alg_bytes (design), alg_flops, compulsory_bytes}] aggregated per kernel name."""
         out = []
         n = self.lib.rgcn_profile_count(self.ctx)
         for i in range(n):
@@ -626,8 +627,10 @@ class Engine:
             ms, by, fl = C.c_double(), C.c_double(), C.c_double()
             self._check(self.lib.rgcn_profile_get(self.ctx, i, name, 64, C.byref(calls), C.byref(ms),
                                                   C.byref(by), C.byref(fl)))
+            cb = C.c_double()
+            self._check(self.lib.rgcn_profile_get_compulsory(self.ctx, i, C.byref(cb)))
             out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
-                        "alg_bytes": by.value, "alg_flops": fl.value})
+                        "alg_bytes": by.value, "alg_flops": fl.value, "compulsory_bytes": cb.value})
         return out
 
     def debug_gemm_time(self, a, b, trans_a=False, trans_b=False, split_k=0, iters=20):

@@ -410,7 +410,9 @@ rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, fl
   for (int b0 = 0; b0 < c->B; b0 += BT) {
     a.b0 = b0;
     a.nbt = c->B - b0 < BT ? c->B - b0 : BT;
-    ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + 2.0 * a.nbt * c->V) + 20.0 * M, 4.0 * M * a.nbt * c->d);
+    const double rows = M < c->V ? M : (double)c->V;     // compulsory: each gathered row of H once
+    ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + 2.0 * a.nbt * c->V) + 20.0 * M, 4.0 * M * a.nbt * c->d,
+                 4.0 * c->d * (rows + 2.0 * a.nbt * c->V) + 20.0 * M);
 #define RGCN_LAUNCH_AGG(VEC, TPR) \
   hipLaunchKernelGGL((k_basis_agg<VEC, TPR>), grid, block, 0, c->stream, a, kLongBlocks)
     if (vec4) {
@@ -440,7 +442,9 @@ rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const
   const int nlb = with_messages ? kLongBlocks : 0;
   dim3 grid(nlb + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
-  ProfScope ps(c, "basis_bwd_gather", 4.0 * c->d * (M * c->B + 4.0 * c->V) + 20.0 * M, 2.0 * M * c->B * c->d);
+  // compulsory: dZ [V, 2B d] once, base / gate / out / out2 once each
+  ProfScope ps(c, "basis_bwd_gather", 4.0 * c->d * (M * c->B + 4.0 * c->V) + 20.0 * M, 2.0 * M * c->B * c->d,
+               4.0 * c->d * (2.0 * c->B * c->V + 4.0 * c->V) + 20.0 * M);
 #define RGCN_LAUNCH_BG(VEC, TPR) \
   hipLaunchKernelGGL((k_basis_bwd_gather<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
   if (vec4) {
@@ -463,7 +467,9 @@ rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* d
     a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr; a.slab = c->slab_dw;
     a.R = c->R; a.B = c->B; a.d = c->d; a.chunk = c->g.chunk;
     const double M = 2.0 * c->g.E / c->world;
-    ProfScope ps(c, "basis_dcoef", 4.0 * c->d * M * (1.0 + c->B), 2.0 * M * c->B * c->d);
+    const double rows = M < c->V ? M : (double)c->V;
+    ProfScope ps(c, "basis_dcoef", 4.0 * c->d * M * (1.0 + c->B), 2.0 * M * c->B * c->d,
+                 4.0 * c->d * (rows + 2.0 * c->B * c->V) + 16.0 * M);
     if (c->d % 4 == 0 && aligned16(Hin) && aligned16(dZ))
       hipLaunchKernelGGL((k_basis_dcoef<4>), dim3(nchunks), dim3(256), 0, c->stream, a);
     else

@@ -230,8 +230,11 @@ rgcn_status block_msg_forward(rgcn_ctx* c, int layer, const float* Hin, float* Y
   a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr;
   a.R2 = 2 * c->R; a.nb = c->nb; a.d = c->d; a.chunk = c->g.chunk; a.G = c->msg_slots;
   const double M = 2.0 * c->g.E / c->world;
-  ProfScope ps(c, "block_msg_fwd", M * (8.0 * c->d + 16.0) + 8.0 * c->R * c->nb * c->sd * c->sd,
-               M * 2.0 * c->d * c->sd);
+  // compulsory: a gathered row of H counts once however many messages read it (at most min(M, V) distinct rows)
+  const double rows = M < c->V ? M : (double)c->V;
+  const double Wb = 8.0 * c->R * c->nb * c->sd * c->sd;
+  ProfScope ps(c, "block_msg_fwd", M * (8.0 * c->d + 16.0) + Wb, M * 2.0 * c->d * c->sd,
+               4.0 * c->d * (rows + M) + 16.0 * M + Wb);
   RGCN_TRY(dispatch_sd(c, [&](auto sdc) {
     constexpr int SD = decltype(sdc)::value;
     hipLaunchKernelGGL((k_block_msg_fwd<SD>), dim3(max_chunks(c)), dim3(c->msg_block), 0, c->stream, a);
@@ -254,8 +257,9 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
     a.R2 = R2; a.nb = c->nb; a.d = c->d; a.chunk = c->g.chunk; a.G = c->msg_slots;
     const size_t lds = (size_t)(c->msg_slots - 1) * per_rel * sizeof(float);
     const double M = 2.0 * c->g.E / c->world;
+    const double rows = M < c->V ? M : (double)c->V;     // distinct rows of H and of D a launch can touch
     ProfScope ps(c, "block_msg_bwd", M * (12.0 * c->d + 20.0) + 16.0 * c->R * per_rel,
-                 M * 4.0 * c->d * c->sd);
+                 M * 4.0 * c->d * c->sd, 4.0 * c->d * (2.0 * rows + M) + 20.0 * M + 16.0 * c->R * per_rel);
     RGCN_TRY(dispatch_sd(c, [&](auto sdc) {
       constexpr int SD = decltype(sdc)::value;
       hipLaunchKernelGGL((k_block_msg_bwd<SD>), dim3(nchunks), dim3(c->msg_block), lds, c->stream, a);

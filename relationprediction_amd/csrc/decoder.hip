@@ -143,7 +143,9 @@ __global__ void k_dec_slots(const int32_t* __restrict__ X, int N, const int32_t*
 // first copy and 0 after it; every further row has its object (fair coin) or else its subject replaced by a uniformly
 // drawn entity.  Same layout and distribution, counter-based generator instead of numpy's streams.
 __global__ void k_negative_sample(const int32_t* __restrict__ batch, int n, int rate, int num_entities, uint64_t seed,
-                                  int32_t* __restrict__ X, float* __restrict__ Y) {
+                                  const uint64_t* __restrict__ seed_offset, int32_t* __restrict__ X,
+                                  float* __restrict__ Y) {
+  if (seed_offset) seed += *seed_offset;      // replayed hipGraphs: replay k draws the corruptions of (captured seed + k)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)n * (rate + 1);
   if (i >= total) return;
@@ -589,7 +591,7 @@ rgcn_status negative_sample(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, in
   if (total <= 0) return RGCN_OK;
   ProfScope ps(c, "negative_sample", 12.0 * n + 16.0 * total, 0);
   hipLaunchKernelGGL(k_negative_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, batch_dev,
-                     (int)n, rate, c->V, seed, X, Y);
+                     (int)n, rate, c->V, seed, c->capturing ? c->replay_counter : nullptr, X, Y);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }
@@ -693,7 +695,10 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
   if (fused) {
     const int T = nvec_e <= 64 ? 1 : (nvec_e <= 128 ? 2 : 4);
     const size_t lds = ((size_t)4 * d + 8) * sizeof(float);
-    ProfScope ps(c, "dec_energy_rel", 12.0 * N * d + 20.0 * N + 4.0 * q.max_chunks * d, 9.0 * N * d);
+    // design: three row gathers per triple (what the kernel asks of L2); compulsory: the code table, the relation
+    // rows and the batch once, the per-triple gradients and chunk partials once
+    ProfScope ps(c, "dec_energy_rel", 12.0 * N * d + 20.0 * N + 4.0 * q.max_chunks * d, 9.0 * N * d,
+                 4.0 * d * ((double)V + R) + 20.0 * N + 4.0 * q.max_chunks * d);
 #define RGCN_LAUNCH_ER(VEC, TT)                                                                                    \
   hipLaunchKernelGGL((k_dec_energy_rel<VEC, TT>), dim3(q.max_chunks), dim3(256), lds, c->stream, codes, Wr, q.X, Y, \
                      q.permr, q.rel_ptr, q.chunk_ptr, N, R, d, q.dx, q.loss_part, q.slab)
@@ -706,7 +711,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.max_chunks, N, d, reg_param,
                        q.loss);
   } else {
-    ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d);
+    ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d, 4.0 * d * ((double)V + R) + 20.0 * N);
     if (vec4)
       hipLaunchKernelGGL((k_dec_energy<4>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
                          R, d, q.dx, q.loss_part);
@@ -730,7 +735,10 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     // (sized for 1024-thread workgroups; four times as many of the 256-thread ones walk the long-row pieces)
     const int nlb = 4 * (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
     dim3 grid(nlb + (V + rpb - 1) / rpb), block(kEntThreads);
-    ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d);
+    // design: two row gathers per incidence (2N incidences) + the row written; compulsory: codes and relation rows
+    // once, the incidence lists and per-triple gradients once, dL/dcodes written once
+    ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d,
+                 4.0 * d * (2.0 * V + R) + 32.0 * N);
 #define RGCN_LAUNCH_EG(VEC, TPR) hipLaunchKernelGGL((k_dec_entity_grad<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
     if (vec4) {
       if (tpr == 64) RGCN_LAUNCH_EG(4, 64); else if (tpr == 128) RGCN_LAUNCH_EG(4, 128); else RGCN_LAUNCH_EG(4, 256);

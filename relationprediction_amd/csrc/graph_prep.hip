@@ -205,22 +205,8 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   }
 }
 
-// The long-row list comes out of k_ptrs in the order its atomics happened to run.  Whatever walks that list in
-// blocks (the long-row workgroups of k_combine, whose per-workgroup column sums feed db_emb) would sum in a
-// run-dependent order: put the list in ascending vertex order.  At most 65536 / 33 entries (minibatch scale): one
-// workgroup, rank by counting in LDS.
-__global__ void __launch_bounds__(1024) k_sort_long_rows(int32_t* __restrict__ long_rows, const int32_t* __restrict__ nlong) {
-  __shared__ int32_t a[2048];
-  const int n = min(*nlong, 2048);
-  for (int i = threadIdx.x; i < n; i += 1024) a[i] = long_rows[i];
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int x = a[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += a[j] < x ? 1 : 0;      // vertices are distinct
-    long_rows[rank] = x;
-  }
-}
+// (The long-row list comes out of k_ptrs in the order its atomics happened to run.  Nothing depends on that order:
+// every long row is summed by exactly one workgroup, in slot order, whichever workgroup draws it.)
 
 __device__ __forceinline__ int upper_bound_dev(const int32_t* a, int n, int x) {
   // first index i in [0,n) with a[i] > x
@@ -295,8 +281,10 @@ __device__ __forceinline__ uint64_t dropout_edge_key(uint64_t seed, uint32_t e) 
 // 64-bit generator is most of the kernel's work; the sweeps below then only compare); otherwise they are recomputed.
 template <bool CACHED>
 __global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict__ batch, int n, int keep, uint64_t seed,
+                                                       const uint64_t* __restrict__ seed_offset,
                                                        const uint8_t* __restrict__ keep_mask,
                                                        int32_t* __restrict__ out, int32_t* errflag) {
+  if (seed_offset) seed += *seed_offset;      // replayed hipGraphs: replay k draws the subset of (captured seed + k)
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wtot[16];
   __shared__ uint64_t prefix_s, thresh_s;
@@ -332,7 +320,10 @@ __global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict
       const int shift = 8 * (7 - pass);
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
+      // both read HERE, a barrier interval before the thread that owns the selected bin rewrites them (reading want_s
+      // beside that write let a later wave's smaller want' select a second bin: round-2 advisor finding)
       const uint64_t prefix = prefix_s;
+      const uint32_t want = want_s;
       for_each_key([&](uint64_t key, int) {
         if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
       });
@@ -352,7 +343,7 @@ __global__ void __launch_bounds__(1024) k_edge_dropout(const int32_t* __restrict
       __syncthreads();
       if (tid < 256) {
         for (int w = 0; w < wid; ++w) incl += wtot[w];
-        const uint32_t want = want_s, excl = incl - h;
+        const uint32_t excl = incl - h;
         if ((excl < want && incl >= want) || (tid == 255 && incl < want)) {
           prefix_s = (prefix << 8) | (uint64_t)tid;
           want_s = want - excl;
@@ -566,10 +557,6 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
                        g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr);
   }
-  if (M > 0 && M <= 65536) {
-    ProfScope ps(c, "prep_sort_long_rows", 8.0 * (M / kLongRow), 0);
-    hipLaunchKernelGGL(k_sort_long_rows, dim3(1), dim3(1024), 0, c->stream, g.long_rows, g.nlong);
-  }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
     ScanJobs jobs;
     jobs.j[0] = {g.indeg, g.cum_in, V, 0};
@@ -596,19 +583,19 @@ rgcn_status graph_build_dropout(rgcn_ctx* c, const int32_t* batch, int64_t n, in
   GraphBufs& g = c->g;
   if (n > 0) {
     ProfScope ps(c, "prep_edge_dropout", 12.0 * n + 12.0 * keep, 0);
+    const uint64_t* seed_off = c->capturing ? c->replay_counter : nullptr;
     if (n <= 32 * 1024) {
-      static bool configured = false;      // up to 64 KB of kept-edge ids beside the static 1.2 KB
-      if (!configured) {
+      if (!c->dropout_lds_configured) {    // up to 64 KB of kept-edge ids beside the static 1.2 KB; per device, so per context
         RGCN_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_dropout<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024));
-        configured = true;
+        c->dropout_lds_configured = true;
       }
       hipLaunchKernelGGL(k_edge_dropout<true>, dim3(1), dim3(1024), 2 * (size_t)std::max<int64_t>(keep, 1), c->stream,
-                         batch, (int)n, (int)keep, seed, keep_mask, g.triples, g.errflag);
+                         batch, (int)n, (int)keep, seed, seed_off, keep_mask, g.triples, g.errflag);
     }
     else
       hipLaunchKernelGGL(k_edge_dropout<false>, dim3(1), dim3(1024), 0, c->stream, batch, (int)n, (int)keep, seed,
-                         keep_mask, g.triples, g.errflag);
+                         seed_off, keep_mask, g.triples, g.errflag);
     RGCN_HIP(c, hipGetLastError());
   }
   return graph_build(c, g.triples, keep);

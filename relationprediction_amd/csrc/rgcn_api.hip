@@ -21,12 +21,13 @@ void set_global_error(const std::string& s) {
 }
 
 // ---------------------------------------------------------------- profiling
-ProfScope::ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops) : c(ctx), idx(-1) {
+ProfScope::ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops, double compulsory) : c(ctx), idx(-1) {
   if (!c->prof_on) return;
   ProfRec r;
   r.name = name;
   r.bytes = bytes;
   r.flops = flops;
+  r.cbytes = compulsory < 0 ? bytes : compulsory;
   for (int k = 0; k < 2; ++k) {
     hipEvent_t e = nullptr;
     if (!c->event_pool.empty()) {
@@ -79,13 +80,14 @@ static rgcn_status profile_collect(rgcn_ctx* c) {
     for (ProfAgg& x : c->prof_agg)
       if (x.name == r.name) { a = &x; break; }
     if (!a) {
-      c->prof_agg.push_back({r.name, 0, 0.0, 0.0, 0.0});
+      c->prof_agg.push_back({r.name, 0, 0.0, 0.0, 0.0, 0.0});
       a = &c->prof_agg.back();
     }
     a->calls += 1;
     a->ms += ms;
     a->bytes += r.bytes;
     a->flops += r.flops;
+    a->cbytes += r.cbytes;
     c->event_pool.push_back(r.e0);
     c->event_pool.push_back(r.e1);
   }
@@ -288,6 +290,9 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   if (f.reserved != 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "reserved must be 0");
   c->V = f.num_entities; c->R = f.num_relations; c->d = f.dim; c->L = f.num_layers; c->kind = f.kind;
   c->rank = f.rank; c->world = f.world;
+  // the library's radix sort takes keys below 2^24 (csr_sort.hip): vertex ids and directed-relation ids
+  if (c->V >= (1 << 24) || 2 * (int64_t)c->R >= (1 << 24))
+    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "EntityCount and 2 x RelationCount must be below 2^24 (sort key range of this build)");
   if ((int64_t)c->V * c->d > (int64_t)1 << 31 || 2 * f.max_edges * (int64_t)c->d > ((int64_t)1 << 40))
     RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "problem too large for this build");
   // messages per relation chunk: 48 at minibatch scale; grows with the capacity so that a full-graph
@@ -1119,6 +1124,7 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
 static rgcn_status prefetch_impl(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int64_t keep, uint64_t eseed) {
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
   if (keep > E) RGCN_FAIL(c, RGCN_ERR_INVALID, "edge dropout: keep outside [0, num_edges]");
+  if (keep >= 0 && E >= ((int64_t)1 << 24)) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "edge dropout: more than 2^24 batch edges");
   if (E > 0 && !tri_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
   // build into the INACTIVE set on the prefetch stream; it only has to wait for the last step that
   // used that set (not for the step currently queued on the main stream)
@@ -1528,6 +1534,12 @@ rgcn_status rgcn_profile_get(rgcn_ctx* c, int32_t i, char* name, int32_t name_ca
   if (total_ms) *total_ms = a.ms;
   if (alg_bytes) *alg_bytes = a.bytes;
   if (alg_flops) *alg_flops = a.flops;
+  return RGCN_OK;
+}
+rgcn_status rgcn_profile_get_compulsory(rgcn_ctx* c, int32_t i, double* compulsory_bytes) {
+  RGCN_NEED(c);
+  if (i < 0 || i >= (int32_t)c->prof_agg.size()) RGCN_FAIL(c, RGCN_ERR_INVALID, "profile index out of range");
+  if (compulsory_bytes) *compulsory_bytes = c->prof_agg[i].cbytes;
   return RGCN_OK;
 }
 

@@ -104,12 +104,12 @@ struct GemmEpilogue {
 struct ProfRec {
   const char* name;
   hipEvent_t e0, e1;
-  double bytes, flops;
+  double bytes, flops, cbytes;
 };
 struct ProfAgg {
   std::string name;
   int64_t calls;
-  double ms, bytes, flops;
+  double ms, bytes, flops, cbytes;
 };
 
 // ---------------------------------------------------------------- parameters
@@ -318,6 +318,7 @@ struct rgcn_ctx {
   void* comm = nullptr;                  // ncclComm_t
   // profiling
   bool prof_on = false;
+  bool dropout_lds_configured = false;   // k_edge_dropout's dynamic-LDS attribute set on this context's device
   std::vector<rgcn::ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   std::vector<rgcn::ProfAgg> prof_agg;
@@ -341,7 +342,10 @@ rgcn_status stream_join(rgcn_ctx* c, int k);
 struct ProfScope {
   rgcn_ctx* c;
   int idx;
-  ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops);
+  // bytes = DESIGN bytes (what the kernel requests from the memory system by construction: gathers counted per use,
+  // staging slabs included); compulsory = every distinct input byte once + every output byte once, < 0:
+  // the same figure.  Roofline fractions are computed on the compulsory bytes.
+  ProfScope(rgcn_ctx* ctx, const char* name, double bytes, double flops, double compulsory = -1.0);
   ~ProfScope();
 };
 

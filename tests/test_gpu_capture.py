@@ -103,6 +103,49 @@ def test_captured_train_step_matches_stepwise_training(native):
         ref.close()
 
 
+def test_captured_minibatch_step_draws_fresh_subsets_per_replay(native):
+    """A captured rgcn_train_step_minibatch_device: replay k draws the edge-dropout subset, the negative samples and the
+    dropout masks of (captured seed + k) -- not the captured draw again -- and equals the same call issued directly
+    with those seeds, bitwise (loss, kept graph, weights)."""
+    eng, params, triples, _ = make_engine(native, E=300)
+    ref, _, _, _ = make_engine(native, E=300)
+    n, keep, rate = len(triples), 150, 3
+    N = n * (rate + 1)
+    held = []
+    try:
+        for e in (eng, ref):
+            e.decoder_reserve(N)
+            e.optimizer_config(lr=0.01, max_grad_norm=1.0)
+            held.append((e.to_device(triples), native.DeviceBuffer(e, 12 * N), native.DeviceBuffer(e, 4 * N)))
+        (B, Xd, Yd), (rB, rX, rY) = held
+        for e, (b, x, y) in zip((eng, ref), held):
+            e.train_step_minibatch_device(b, n, keep, 7, rate, 8, x, y, seed=9, reg_param=0.01)       # warm-up
+        eng.sync()
+        eng.capture_begin()
+        eng.train_step_minibatch_device(B, n, keep, 100, rate, 200, Xd, Yd, seed=300, reg_param=0.01)
+        gid = eng.capture_end()
+        graphs = []
+        for launch in (1, 2, 3):
+            eng.graph_launch(gid)
+            ref.train_step_minibatch_device(rB, n, keep, 100 + launch, rate, 200 + launch, rX, rY, seed=300 + launch,
+                                            reg_param=0.01)
+            assert eng.loss() == ref.loss(), launch
+            g = eng.graph_edges()
+            assert np.array_equal(g, ref.graph_edges())
+            assert np.array_equal(Xd.download(np.int32, (N, 3)), rX.download(np.int32, (N, 3)))
+            graphs.append(g.tobytes())
+        assert len(set(graphs)) == 3                      # three replays, three different kept subsets
+        got, want = eng.get_params(), ref.get_params()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        for t in held:
+            for b in t:
+                b.free()
+        eng.close()
+        ref.close()
+
+
 def test_config5_fb15k_train_step_in_a_hipgraph(native):
     """BASELINE config 5 on one GPU: FB15k's space (V 14,951 / R 1,345), block kind d = 500, E_g = 15,000 real
     valid triples, the DistMult decoder on N = 330,000 triples (30,000 positives + 10 corruptions each), clip and

@@ -41,45 +41,70 @@ def test_sharded_steps_across_processes(collective, world, kind, nb):
     assert "SHARDED-OK world=%d kind=%s" % (world, kind) in r.stdout
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_multi_rank_prints_one_json_line_last(collective, world):
-    r = launch(world, 29650 + world, ["bench.py", "--gpus", str(world), "--steps", "4", "--warmup", "1",
-                                      "--cpu-steps", "0"], collective, {"RGCN_BENCH_SHARE_GPU": "1"})
+def check_multi_rank_line(r, world):
     assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "elastic" not in l and "torch/distributed" not in l)[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines[-1]) < 8192                                 # the driver keeps an 8 KB tail: the line must fit
     out = json.loads(lines[-1])                                  # the JSON line is the LAST line on stdout
     assert sum(1 for l in lines if l.startswith("{")) == 1
     assert out["n_gpus"] == world and out["steps"] == 4 and out["value"] > 0
     assert out["config"]["parallelism"].startswith("relation-sharded x%d" % world)
-    names = {k["kernel"] for k in out["kernels"]}
-    assert out["roofline"] and {"rccl_allreduce", "rccl_reduce_scatter", "rccl_all_gather"} <= names
-    assert out["comm_ms_per_step"] > 0
+    assert out["roofline"] and out["comm_ms_per_step"] > 0
+    with open(os.path.join(ROOT, out["details"])) as f:          # the per-kernel tables live in the side file
+        names = {k["kernel"] for k in json.load(f)["kernels"]}
+    assert {"rccl_allreduce", "rccl_reduce_scatter", "rccl_all_gather"} <= names
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_prints_one_json_line_last(collective, world):
+    r = launch(world, 29650 + world, ["bench.py", "--gpus", str(world), "--steps", "4", "--warmup", "1",
+                                      "--cpu-steps", "0"], collective, {"RGCN_BENCH_SHARE_GPU": "1"})
+    check_multi_rank_line(r, world)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_spawns_its_own_ranks_without_a_launcher(collective, world):
+    """`python3 bench.py --gpus N` as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the script starts
+    its N ranks itself and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(RGCN_RCCL_LIBRARY=collective, RGCN_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+                        "--cpu-steps", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    check_multi_rank_line(r, world)
 
 
 def test_bench_single_gpu_line_carries_every_section():
-    """The driver's call with small counts: ONE JSON line (the last line of stdout) with the contract keys, the
-    roofline and cpu_baseline objects, the other BASELINE configurations ("workloads"), the device train steps
-    ("train_steps", config 5's captured step among them) and the evaluation pass ("evaluation")."""
-    import json
-    import subprocess
-    import sys
+    """The driver's call with small counts: ONE compact JSON line (the last line of stdout, under 8 KB) with the contract
+    keys, the roofline and cpu_baseline objects, one-line summaries of the other BASELINE configurations ("workloads"),
+    the device train steps ("train_steps", config 5's captured step among them) and the evaluation pass ("evaluation");
+    the per-kernel tables in bench_details.json."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--extra-steps", "2",
                         "--cpu-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines[-1]) < 8192, len(lines[-1])
     d = json.loads(lines[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["config"]["workload"] == "fb237_block" and d["value"] > 0
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert d["config"]["norm_mode"].startswith("intended")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "compulsory_bytes", "design_bytes"} <= set(d["roofline"])
+    assert 0 < d["roofline"]["frac"] <= 1
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
-    assert [w["config"]["workload"] for w in d["workloads"]] == ["fb237_basis_b2", "fb237_basis_b5", "wn18_block",
-                                                                 "fb15k_block", "fb237_block_fullgraph",
-                                                                 "fb237_block_traingraph"]
-    assert all(w["ms_per_step"] > 0 and w["roofline"] for w in d["workloads"])
+    assert d["cpu_baseline_reference_code"]["kind"].startswith("reference-code") \
+        and d["cpu_baseline_reference_code"]["measured_in_this_run"] is False
+    assert [w["workload"] for w in d["workloads"]] == ["fb237_basis_b2", "fb237_basis_b5", "wn18_block", "fb15k_block",
+                                                       "fb237_block_fullgraph", "fb237_block_traingraph"]
+    assert all(w["ms_per_step"] > 0 and w["kernel"] and 0 < w["frac"] <= 1 for w in d["workloads"])
     assert [t["workload"] for t in d["train_steps"]] == ["fb237_block_train_step", "fb15k_block_train_step"]
     for t in d["train_steps"]:
-        assert t["minibatch_step"]["ms_per_step"] > 0 and t["minibatch_step"]["kernels"]
-        assert t["captured_step"]["ms_per_step_hipgraph_replay"] > 0 and t["captured_step"]["ms_per_step_stream_launched"] > 0
+        assert t["ms_per_step"] > 0 and t["hipgraph_ms"] > 0 and t["stream_ms"] > 0 and t["top"]
     assert d["evaluation"]["ranked_triples_per_s"] > 0 and d["evaluation"]["encode_full_graph_ms"] > 0
+    with open(os.path.join(ROOT, d["details"])) as f:
+        full = json.load(f)
+    # no kernel of any workload or train step claims more than its roofline
+    tables = [full["kernels"]] + [w["kernels"] for w in full["workloads"]] + \
+             [t["minibatch_step"]["kernels"] for t in full["train_steps"]]
+    assert all(k["frac"] <= 1.0 for tab in tables for k in tab), [k for tab in tables for k in tab if k["frac"] > 1.0]
+    assert all({"compulsory_bytes", "design_bytes", "traffic"} <= set(k) for k in full["kernels"])
