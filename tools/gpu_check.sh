@@ -34,19 +34,4 @@ print("step_roofline", {k: v for k, v in (d.get("step_roofline") or {}).items() 
 for k in d["kernels"]:
     print("   %-22s x%.0f %7.1f us (pipelined %7.1f) %s frac %.3f  comp %.1f MB design %.1f MB pmc %s" % (k["kernel"], k["launches_per_step"], k["avg_us"], k["avg_us_in_pipeline"], k["bound"], k["frac"], k["compulsory_bytes"] / 1e6, k["design_bytes"] / 1e6, k["traffic"]))
 PY
-import json
-d = json.loads(open("gpurun_out/bench_$TAG.json").read().strip().splitlines()[-1])
-def line(o):
-    r = o.get("roofline") or {}
-    return "%-24s %8.3f ms/step %10.2f M edges/s   top kernel %-16s %6.1f us frac %.3f" % (
-        o["config"]["workload"], o["ms_per_step"], o["value"] / 1e6, r.get("kernel"), r.get("avg_us", 0), r.get("frac", 0))
-print(line(d))
-for o in d.get("workloads", []):
-    print(line(o))
-for t in d.get("train_steps", []):
-    print("  ", t["workload"], t.get("minibatch_step"), t.get("captured_step"))
-print("cpu", d.get("cpu_baseline"))
-for k in d["kernels"]:
-    print("   %-22s x%.0f %7.1f us (pipelined %7.1f) %s frac %.3f" % (k["kernel"], k["launches_per_step"], k["avg_us"], k["avg_us_in_pipeline"], k["bound"], k["frac"]))
-PY
 tail -n 20 gpurun_out/bench_$TAG.err
