@@ -22,7 +22,9 @@ Rank 0 prints ONE COMPACT JSON line LAST on stdout (a few KB: tests hold it unde
                   WN18 and FB15k shapes (configs 4 and 5), the 38,001-edge and the 272,115-edge full graphs,
   "train_steps":  (same run) whole training iterations on the device at the FB15k-237 and FB15k sizes: the minibatch
                   step train.py launches and configs[4]'s hipGraph-captured train step, replayed against stream-launched,
-  "evaluation":   (same run) test-mode encoding of the 272,115-edge graph, raw + filtered ranks of 2,000 triples.
+  "evaluation":   (same run) test-mode encoding of the 272,115-edge graph, raw + filtered ranks of 2,000 triples,
+  "train_loop":   (same run) the reference's whole iteration through the training driver: host neighbourhood sampler
+                  (k builder threads) + upload + device step + loss read-back: ms / iteration, device idle fraction.
 Everything else -- the per-kernel tables of every workload and train step, notes -- goes to bench_details.json next to
 this file (and to gpurun_out/ when that directory exists), never to the result line.
 
@@ -590,6 +592,120 @@ def measure_train_step(name, args, steps, warmup):
     return out
 
 
+TRAIN_LOOP_SETTINGS = """[Encoder]
+	Name=gcn_basis
+	DropoutKeepProbability=0.8
+	InternalEncoderDimension=500
+	NumberOfBasisFunctions=100
+	NumberOfLayers=2
+	UseInputTransform=Yes
+	UseOutputTransform=No
+	Concatenation=Yes
+[Decoder]
+	Name=bilinear-diag
+	RegularizationParameter=0.01
+[Shared]
+	CodeDimension=500
+[Optimizer]
+	MaxGradientNorm=1
+	ReportTrainLossEvery=100000
+	MaxIterations=%d
+	[Algorithm]
+		Name=Adam
+		learning_rate=0.01
+[General]
+	NegativeSampleRate=10
+	GraphSplitSize=0.5
+	ExperimentName=/tmp/rgcn_bench_train_loop
+	GraphBatchSize=30000
+[Evaluation]
+	Metric=MRR
+"""
+
+
+def measure_train_loop(args, device_step_ms, iterations=150, workers=(0, 8)):
+    """The reference's WHOLE training iteration (code/train.py:161-247 + optimization/optimize.py:81-88) through this
+    repository's driver, at settings/gcn_block.exp's values on the 272,115-edge synthetic FB15k-237 training graph: the
+    neighbourhood edge sampler (30,000 picks, the reference's random process, on the HOST: librgcn.so's O(log V)
+    sampler), upload of the graph batch, then ONE device call (edge dropout + negatives + prep + encoder + DistMult +
+    clip + Adam) and the loss read back every iteration, as the reference's loop does.  Reported: ms per iteration with
+    the batches built in line and by k background threads, the host's cost of building one batch, and the fraction of
+    the iteration the device is idle -- row f4 of SURVEY 8 measured instead of asserted."""
+    import contextlib
+    import tempfile
+    import numpy as np
+    from relationprediction_amd import train
+    from relationprediction_amd.common import model_builder, optimizer_parameter_parser, settings_reader
+    from relationprediction_amd.optimization.optimize import build_hip
+    V, R, E = 14541, 237, 272115
+    triples = load_graph("synth:fb237_valid_test:%d" % E)
+    out = {"workload": "fb237_block_train_loop", "train_graph_edges": E, "graph_batch": 30000, "graph_edges": 15000,
+           "decoder_triples": 330000, "iterations": iterations,
+           "sampler": "host, the reference's process (train.py:161-198) in O(log V) per pick"}
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(sys.stderr):
+        def build(max_iterations):
+            path = os.path.join(tmp, "loop.exp")
+            with open(path, "w") as f:
+                f.write(TRAIN_LOOP_SETTINGS % max_iterations)
+            s = settings_reader.read(path)
+            general = s['General']
+            general.put('EntityCount', V)
+            general.put('RelationCount', R)
+            general.put('EdgeCount', E)
+            for part in ('Encoder', 'Decoder'):
+                s[part].merge(s['Shared'])
+                s[part].merge(general)
+            s['Optimizer'].merge(general)
+            return s, general
+        s, general = build(iterations)
+        encoder = model_builder.build_encoder(s['Encoder'], triples)
+        model = model_builder.build_decoder(encoder, s['Decoder'])
+        t_func = train.make_transform(triples, general, encoder, device_negatives=True, device_dropout=True)
+        model.preprocess(triples)
+        model.register_for_test(triples)
+        model.initialize_train()
+        try:
+            eng = model.get_runtime().engine
+            eng.set_gemm_mode(args.gemm_mode)
+            # host cost of one batch (sampler + bookkeeping), single thread
+            ts = []
+            for i in range(6):
+                t0 = time.perf_counter()
+                t_func.seeded(triples, 1000 + i)
+                ts.append(time.perf_counter() - t0)
+            out["host_batch_build_ms"] = round(float(np.median(ts[1:])) * 1e3, 3)
+
+            def fit(n_iter, nworkers):
+                s2, _ = build(n_iter)
+                opp = optimizer_parameter_parser.Parser(s2['Optimizer'])
+                opp.set_save_function(lambda p: None)
+                opp.set_sample_transform_function(t_func)
+                opt = build_hip(model, [p for p in opp.get_parametrization() if p[0] != 'ModelSaver'],
+                                batch_workers=nworkers)
+                np.random.seed(0)
+                t0 = time.perf_counter()
+                n = opt.fit(triples)
+                return (time.perf_counter() - t0) * 1e3 / max(n, 1), n
+            fit(12, 0)                                    # warm-up: lazy allocations, first sampler state
+            per_worker = {}
+            for w in workers:
+                ms, n = fit(iterations, w)
+                per_worker[str(w)] = round(ms, 4)
+            out["ms_per_iteration_by_builder_threads"] = per_worker
+            dev_ms = float(device_step_ms)      # the same device call, launched back to back without host waits (train_steps)
+            out["device_step_ms"] = round(dev_ms, 4)
+            best = min(per_worker.values())
+            out["ms_per_iteration"] = best
+            out["iterations_per_s"] = round(1e3 / best, 1)
+            out["device_idle_frac"] = round(max(0.0, 1.0 - dev_ms / best), 4)
+            out["loss_after"] = round(float(model.device_loss()), 6)
+        finally:
+            rt = model.get_runtime()
+            if rt is not None and getattr(rt, "engine", None) is not None:
+                rt.engine.close()
+    return out
+
+
 def measure_evaluation(args, queries=2000):
     """The evaluation half of the reference's loop ("next" row f3 of SURVEY 8; code/common/evaluation.py:148-153,349-389,
     model.py:59-81): one test-mode encoding of the full training graph (272,115 edges, SURVEY 8d graph B) and raw +
@@ -709,6 +825,9 @@ def compact_line(out):
     ev = out.get("evaluation")
     line["evaluation"] = ({k: ev[k] for k in ("graph_edges", "queries", "encode_full_graph_ms", "rank_both_sides_ms",
                                                "ranked_triples_per_s")} if ev else None)
+    tl = out.get("train_loop")
+    line["train_loop"] = ({k: tl[k] for k in ("ms_per_iteration", "iterations_per_s", "device_step_ms", "device_idle_frac",
+                                               "host_batch_build_ms", "ms_per_iteration_by_builder_threads")} if tl else None)
     line["details"] = out.get("details")
     return line
 
@@ -764,10 +883,13 @@ def main():
         for w in TRAIN_STEP_WORKLOADS:
             train_steps.append(measure_train_step(w, args, args.extra_steps, min(args.warmup, 5)))
     evaluation = measure_evaluation(args) if widen else None
+    train_loop = (measure_train_loop(args, train_steps[0]["minibatch_step"]["ms_per_step"],
+                                     iterations=max(20, 6 * args.extra_steps)) if widen else None)
     if rk.rank == 0:
         out["workloads"] = extras
         out["train_steps"] = train_steps
         out["evaluation"] = evaluation
+        out["train_loop"] = train_loop
         if rk.world == 1 and args.workload == "fb237_block":
             out["cpu_baseline_reference_code"] = reference_code_baseline()
     if rk.world > 1 and rk.rank == 0 and os.path.exists(rk.rdv_path):

@@ -355,13 +355,18 @@ rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises *
  * With overlap off every kernel runs alone on the main stream: per-kernel durations are exclusive. */
 rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
 
-/* The self-loop GEMM with the combine step as its epilogue (default OFF; RGCN_FUSE=1 in the environment turns it on
- * at create): H' = relu(dropout(H.W_self) + sum of the row's messages) leaves ONE kernel and the product never
- * travels to HBM and back (58 MB less per layer pass at FB15k-237 size); likewise the backward (dS.W_self^T + message
- * gradients) * relu'.  Block kind, one GPU, split arithmetic, minibatch-sized graphs; everything else runs the
- * two-kernel form.  Both forms give bitwise the same result; on MI355X the fused kernel is the slower one (87-89 us
- * against 80-83 for the pair), hence the default. */
-rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t on);
+/* Form of the block-diagonal layer (ConcatGcn.compute_messages + combine_messages, gcn_basis_concat.py:35-83, and
+ * their gradient) on one GPU; RGCN_FUSE in the environment sets it at create.  All three give bitwise the same
+ * activations and gradients (tests/test_gpu_parity.py::test_fused_layer_kernel_equals_the_two_kernel_form).
+ *   0 : (default) relation-major message kernel -> [2E,d] message buffer -> row-major reduce (k_combine)
+ *   1 : as 0, with the reduce as the epilogue of the self-loop GEMM (the product never travels; measured slower)
+ *   2 : the single-pass block SpMM (csrc/block_spmm.hip): ONE kernel per layer and direction gathers the partner rows
+ *       through the incidence CSR, applies the sd x sd blocks from an LDS-resident weight table (needs 2R x sd^2 floats
+ *       of LDS: up to ~500 relations at sd = 5), reduces each row's messages in k_combine's order and applies self-loop
+ *       term, dropout and relu / relu' -- no message buffer at all, 60 % less HBM traffic, and on MI355X 2.2x SLOWER
+ *       than form 0 (instruction- and latency-bound at 8 waves per CU; profiles/r03_block_spmm_ab.md), hence opt-in.
+ * Other kinds, sharded contexts and weight tables that do not fit run form 0 whatever the setting. */
+rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t mode);
 
 /* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.
  *   6 : (default) every fp32 operand is split exactly into three bf16 numbers hi + mid + lo (round to

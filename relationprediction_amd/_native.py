@@ -604,8 +604,9 @@ class Engine:
     def set_overlap(self, on=True):
         self._check(self.lib.rgcn_set_overlap(self.ctx, 1 if on else 0))
 
-    def set_fusion(self, on=True):
-        self._check(self.lib.rgcn_set_fusion(self.ctx, 1 if on else 0))
+    def set_fusion(self, mode=2):
+        """form of the block layer: 0 two kernels + message buffer, 1 GEMM-epilogue fusion, 2 single-pass block SpMM"""
+        self._check(self.lib.rgcn_set_fusion(self.ctx, int(mode)))
 
     def set_gemm_mode(self, mode):
         """0 = fp32 MFMA, 9 / 6 = exact bf16 operand split with 9 / 6 partial products (include/rgcn.h)."""

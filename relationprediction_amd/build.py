@@ -24,7 +24,7 @@ LIB = os.path.join(LIBDIR, "librgcn.so")
 # tools/ and the dense-contraction tests; the product library has none of them
 LIB_DEVTOOLS = os.path.join(LIBDIR, "librgcn_devtools.so")
 ARCH = "gfx950"
-SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "basis.hip",
+SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "block_spmm.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h"),
            os.path.join(ROOT, "include", "rgcn_devtools.h")]

@@ -83,7 +83,8 @@ __global__ void k_block_msg_fwd(MsgArgs a) {
   }
 }
 
-template <int SD>
+// ZOUT = false: only the weight-gradient slabs (the row gradients come from the single-pass layer kernel)
+template <int SD, bool ZOUT>
 __global__ void k_block_msg_bwd(MsgArgs a) {
   extern __shared__ float red[];   // [(G-1)][SD*SD][nb]
   const int bid = blockIdx.x;
@@ -98,26 +99,30 @@ __global__ void k_block_msg_bwd(MsgArgs a) {
 #pragma unroll
   for (int k = 0; k < SD * SD; ++k) dw[k] = 0.0f;
   if (active) {
+    if constexpr (ZOUT) {
 #pragma unroll
-    for (int k = 0; k < SD * SD; ++k) w[k] = a.W[((size_t)rel * SD * SD + k) * a.nb + b];
+      for (int k = 0; k < SD * SD; ++k) w[k] = a.W[((size_t)rel * SD * SD + k) * a.nb + b];
+    }
     const int col = b * SD;
     for (int j = beg + g; j < end; j += a.G) {
       const int src = a.m_src[j];
       const int dst = a.m_dst[j];
-      const int slot = a.m_slot[j];
+      const int slot = ZOUT ? a.m_slot[j] : 0;
       const float nrm = a.m_norm[j];
       const float* xp = a.Hin + (size_t)src * a.d + col;
       const float* gp = a.D + (size_t)dst * a.d + col;
       float x[SD], gr[SD];
 #pragma unroll
       for (int q = 0; q < SD; ++q) { x[q] = xp[q]; gr[q] = gp[q] * nrm; }
-      float* zp = a.out + (size_t)slot * a.d + col;
+      if constexpr (ZOUT) {
+        float* zp = a.out + (size_t)slot * a.d + col;
 #pragma unroll
-      for (int q = 0; q < SD; ++q) {
-        float z = 0.0f;
+        for (int q = 0; q < SD; ++q) {
+          float z = 0.0f;
 #pragma unroll
-        for (int i = 0; i < SD; ++i) z = fmaf(w[i * SD + q], gr[i], z);   // (T^T g)_j
-        zp[q] = z;
+          for (int i = 0; i < SD; ++i) z = fmaf(w[i * SD + q], gr[i], z);   // (T^T g)_j
+          zp[q] = z;
+        }
       }
 #pragma unroll
       for (int i = 0; i < SD; ++i)
@@ -258,12 +263,22 @@ rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const f
     const size_t lds = (size_t)(c->msg_slots - 1) * per_rel * sizeof(float);
     const double M = 2.0 * c->g.E / c->world;
     const double rows = M < c->V ? M : (double)c->V;     // distinct rows of H and of D a launch can touch
-    ProfScope ps(c, "block_msg_bwd", M * (12.0 * c->d + 20.0) + 16.0 * c->R * per_rel,
-                 M * 4.0 * c->d * c->sd, 4.0 * c->d * (2.0 * rows + M) + 20.0 * M + 16.0 * c->R * per_rel);
-    RGCN_TRY(dispatch_sd(c, [&](auto sdc) {
-      constexpr int SD = decltype(sdc)::value;
-      hipLaunchKernelGGL((k_block_msg_bwd<SD>), dim3(nchunks), dim3(c->msg_block), lds, c->stream, a);
-    }));
+    if (Zbuf != nullptr) {
+      ProfScope ps(c, "block_msg_bwd", M * (12.0 * c->d + 20.0) + 16.0 * c->R * per_rel,
+                   M * 4.0 * c->d * c->sd, 4.0 * c->d * (2.0 * rows + M) + 20.0 * M + 16.0 * c->R * per_rel);
+      RGCN_TRY(dispatch_sd(c, [&](auto sdc) {
+        constexpr int SD = decltype(sdc)::value;
+        hipLaunchKernelGGL((k_block_msg_bwd<SD, true>), dim3(nchunks), dim3(c->msg_block), lds, c->stream, a);
+      }));
+    } else {
+      // weight gradients only: two row gathers per message, one slab per chunk
+      ProfScope ps(c, "block_dw_msgs", M * (8.0 * c->d + 16.0) + 8.0 * c->R * per_rel, M * 2.0 * c->d * c->sd,
+                   4.0 * c->d * 2.0 * rows + 16.0 * M + 8.0 * c->R * per_rel);
+      RGCN_TRY(dispatch_sd(c, [&](auto sdc) {
+        constexpr int SD = decltype(sdc)::value;
+        hipLaunchKernelGGL((k_block_msg_bwd<SD, false>), dim3(nchunks), dim3(c->msg_block), lds, c->stream, a);
+      }));
+    }
     RGCN_HIP(c, hipGetLastError());
   }
   return RGCN_OK;

@@ -470,7 +470,7 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   RGCN_TRY(dalloc(c, &g.m_dslot, M));
   RGCN_TRY(dalloc(c, &g.m_sslot, M));
   RGCN_TRY(dalloc(c, &g.m_norm, M));
-  if (c->kind == RGCN_KIND_BASIS) {
+  if (c->kind == RGCN_KIND_BASIS || block_spmm_available(c)) {      // slot-ordered message lists (row-major gathers)
     RGCN_TRY(dalloc(c, &g.d_src, M));
     RGCN_TRY(dalloc(c, &g.d_rel, M));
     RGCN_TRY(dalloc(c, &g.d_norm, M));
@@ -570,7 +570,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
     hipLaunchKernelGGL(k_build_msgs, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R,
                        c->cfg.norm_mode, g.permr, g.rel_ptr, g.pos, g.indeg, g.outdeg, g.cum_in,
                        g.cum_out, g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.keyr_s,
-                       c->kind == RGCN_KIND_BASIS ? 1 : 0, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel, g.s_norm);
+                       g.d_src != nullptr ? 1 : 0, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel, g.s_norm);
   }
   RGCN_HIP(c, hipGetLastError());
   g.ready = true;

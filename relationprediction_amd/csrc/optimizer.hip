@@ -217,6 +217,7 @@ rgcn_status optimizer_apply(rgcn_ctx* c) {
   double total = 0;
   RGCN_TRY(build_table(c, tab, &nrep, &total));
   o.t += 1;        // host-side mirror (exact only while no captured graph is replayed)
+  c->weights_version += 1;   // derived copies of the weights (block-major tables) are stale after this step
   {
     ProfScope ps(c, "opt_clip_scale", 4.0 * tab.nblocks, 0);
     hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, c->stream, o.part, nrep,

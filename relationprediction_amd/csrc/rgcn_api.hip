@@ -246,7 +246,7 @@ static void free_all(rgcn_ctx* c) {
       lb.gwself = nullptr;
       if (c->kind == RGCN_KIND_BASIS) lb.grel = nullptr;
     }
-    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias);
+    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wbm);
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
@@ -351,8 +351,11 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     // Off by default: measured on MI355X (profiles/r02_fused_layer_ab.log) the fused kernel takes 87-89 us where GEMM +
     // combine take 80-83 -- all workgroups reach the gather epilogue at once, with 8 waves per CU where k_combine runs
     // 32 -- although it moves 58 MB less per layer pass.  RGCN_FUSE=1 / rgcn_set_fusion turn it on.
+    // RGCN_FUSE = 0 / 1 / 2 picks the form of the block layer (rgcn_set_fusion).  Default 0, the two-kernel form: both
+    // fused forms are bitwise equal to it and both measured slower on MI355X (profiles/r02_fused_layer_ab.log: GEMM
+    // epilogue 87-89 us against 80-83; profiles/r03_block_spmm_ab.md: single-pass SpMM 125-160 us against 57 forward)
     const char* fu = getenv("RGCN_FUSE");
-    c->fuse = fu && atoi(fu) != 0;
+    c->fuse = fu ? atoi(fu) : 0;
     const char* m = getenv("RGCN_GEMM_MODE");
     const int mode = m ? atoi(m) : 6;
     c->gemm_mode = (mode == 0 || mode == 3 || mode == 6 || mode == 9) ? mode : 6;
@@ -388,6 +391,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
       RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
       add_param(c, "W_f" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel, lb.grel, LAYOUT_BLOCK_T);
       add_param(c, "W_b" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel + per_dir, lb.grel + per_dir, LAYOUT_BLOCK_T);
+      if (block_spmm_available(c)) RGCN_TRY(dmalloc(c, &lb.wbm, block_spmm_weight_floats(c)));
     } else {
       const size_t per_dir = (size_t)c->B * d * d;
       RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));
@@ -412,6 +416,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_TRY(dmalloc(c, &c->w_rel, Vd));
   RGCN_TRY(dmalloc(c, &c->g_rel, Vd));
   add_param(c, "W_relation", {(int64_t)V, (int64_t)d}, c->w_rel, c->g_rel, LAYOUT_PLAIN);
+  if (c->fuse < 0 || c->fuse > 2) c->fuse = 0;
   c->H.assign(c->L + 1, nullptr);
   for (int l = 0; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->H[l], Vd));
   RGCN_TRY(dmalloc(c, &c->self_buf, Vd));
@@ -467,6 +472,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
 
 // ---------------------------------------------------------------- layout conversion
 static rgcn_status param_upload(rgcn_ctx* c, const Param& p, float* dst, const float* host) {
+  c->weights_version += 1;       // derived copies (the block-major weight tables) are stale now
   if (p.layout == LAYOUT_PLAIN) return to_dev(c, dst, host, sizeof(float) * p.count);
   RGCN_TRY(to_dev(c, c->stage, host, sizeof(float) * p.count));
   if (p.layout == LAYOUT_BLOCK_T) RGCN_TRY(block_to_device_layout(c, c->stage, dst, c->R));
@@ -520,8 +526,11 @@ static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
 // The self-loop GEMM takes the combine as its epilogue: block kind, one GPU, split arithmetic (the fp32-MFMA kernel
 // keeps the two-kernel form), 16-byte rows, minibatch scale (no giant rows).
 static bool fused_layer(const rgcn_ctx* c) {
-  return c->fuse && c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->gemm_mode != 0 && c->d % 4 == 0 && !c->g.giant_on;
+  return c->fuse == 1 && c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->gemm_mode != 0 && c->d % 4 == 0 && !c->g.giant_on;
 }
+
+// The block layer as ONE pass over the incidence CSR (block_spmm.hip): block kind, one GPU, weight table in LDS.
+static bool spmm_layer(const rgcn_ctx* c) { return c->fuse == 2 && block_spmm_available(c); }
 
 static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
@@ -530,7 +539,19 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
-  if (fused_layer(c)) {
+  if (spmm_layer(c)) {
+    // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
+    // the incidence CSR (no message buffer)
+    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, V, d, d, Hin, d, c->layers[l].wself, d, c->self_buf, d, 1));
+    CombineArgs a;
+    a.add = nullptr; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
+    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.gate = nullptr; a.V = V; a.d = d;
+    a.relu = l < c->L ? 1 : 0;
+    a.row_lo = 0; a.row_hi = V;
+    a.drop = make_drop(c, l, true);
+    a.drop2 = make_drop(c, l, false);
+    RGCN_TRY(block_spmm(c, "block_spmm_fwd", l, false, Hin, a));
+  } else if (fused_layer(c)) {
     // messages -> ONE kernel: H' = relu(dropout(H.W_self) + sum of the row's messages)
     RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
     GemmEpilogue e;
@@ -649,7 +670,27 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
   }
 
-  if (fused_layer(c)) {
+  if (c->dw_pending) {       // the previous layer's weight-gradient kernel reads the D buffer this layer may overwrite
+    RGCN_TRY(stream_join(c, 0));
+    c->dw_pending = false;
+  }
+  if (spmm_layer(c)) {
+    // weight gradients of the relations (dW_r = sum n g (x) x, relation-major, two row gathers per message) on side
+    // stream 0 beside the self-loop GEMMs; the row gradients come from the single-pass kernel behind G = dS . W_self^T
+    {
+      StreamScope side(c, 0);
+      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
+      RGCN_TRY(block_dw_reduce(c, l));
+      c->dw_pending = side.active;
+    }
+    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, V, d, d, c->bwd_dS, d, lb.wself, d, c->self_buf, d, 1));
+    {
+      StreamScope side(c, 1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, V, Hin, d, c->bwd_dS, d, lb.gwself, d,
+                        auto_split_k(d, d, V)));
+    }
+    RGCN_TRY(block_spmm(c, "block_spmm_bwd", l, true, c->bwd_D, a));
+  } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
     // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
     // side streams
@@ -749,6 +790,7 @@ static rgcn_status bwd_end(rgcn_ctx* c) {
   if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
   // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
   RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
+  c->dw_pending = false;
   return stream_join(c, 0);   // trailing per-relation dW reductions
 }
 
@@ -1490,9 +1532,10 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
   return RGCN_OK;
 }
 
-rgcn_status rgcn_set_fusion(rgcn_ctx* c, int32_t on) {
+rgcn_status rgcn_set_fusion(rgcn_ctx* c, int32_t mode) {
   RGCN_NEED(c);
-  c->fuse = on != 0;
+  if (mode < 0 || mode > 2) RGCN_FAIL(c, RGCN_ERR_INVALID, "fusion mode must be 0, 1 or 2");
+  c->fuse = mode;
   return RGCN_OK;
 }
 

@@ -141,6 +141,10 @@ struct LayerBufs {
   float* gwself = nullptr;
   float* bias = nullptr;    // [d], unused by the math
   float* gbias = nullptr;
+  // BLOCK, single-pass layer kernel (block_spmm.hip): block-major copy of wrel, [nb][2R][sd*sd padded to 4], and the
+  // weights version it was built from
+  float* wbm = nullptr;
+  uint64_t wbm_version = ~0ull;
 };
 
 struct GraphBufs {
@@ -245,7 +249,11 @@ struct rgcn_ctx {
                                                                // 2 for the decoder's relation gradient (runs beside the backward pass)
   hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
-  bool fuse = false;                      // self-loop GEMM with the combine as its epilogue (block kind, one GPU, split arithmetic)
+  // block kind, one GPU: 0 = message kernel + k_combine (two kernels, [2E,d] message buffer), 1 = self-loop GEMM with
+  // the combine as its epilogue, 2 = single-pass block SpMM (block_spmm.hip; no message buffer at all)
+  int fuse = 0;
+  uint64_t weights_version = 1;           // bumped whenever a parameter value changes (set_param, Adam)
+  bool dw_pending = false;                // a dW-only message-gradient kernel of the previous backward layer is still on side stream 0
   std::string err;
 
   std::vector<rgcn::Param> params;
@@ -387,10 +395,18 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);
 rgcn_status block_msg_forward(rgcn_ctx* c, int layer, const float* Hin, float* Ybuf);
+// Zbuf == nullptr: the per-relation weight gradients only (the single-pass layer kernel computes the row gradients)
 rgcn_status block_msg_backward(rgcn_ctx* c, int layer, const float* Hin, const float* D, float* Zbuf);
 rgcn_status block_dw_reduce(rgcn_ctx* c, int layer);
 rgcn_status block_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst, int R);
 rgcn_status block_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev, int R);
+
+// ---- block_spmm.hip: the block layer in ONE pass per direction (gather, sd x sd products, segmented row sums, self-loop
+// term, dropout, relu / relu'), no message buffer
+struct CombineArgs;
+bool block_spmm_available(const rgcn_ctx* c);
+size_t block_spmm_weight_floats(const rgcn_ctx* c);
+rgcn_status block_spmm(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca);
 
 // ---- basis.hip
 rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z);

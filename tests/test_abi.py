@@ -148,7 +148,10 @@ def test_bench_result_line_stays_compact_and_self_spawns():
            "train_steps": [{"workload": "w" * 24, "minibatch_step": {"ms_per_step": 1.2, "edges_per_s": 1e7, "kernels": kern},
                             "captured_step": {"ms_per_step_hipgraph_replay": 1.2, "ms_per_step_stream_launched": 1.2}}] * 2,
            "evaluation": {"graph_edges": 272115, "queries": 2000, "encode_full_graph_ms": 1.6, "rank_both_sides_ms": 2.5,
-                          "ranked_triples_per_s": 8e5, "note": "n" * 300}, "details": "bench_details.json"}
+                          "ranked_triples_per_s": 8e5, "note": "n" * 300}, "details": "bench_details.json",
+           "train_loop": {"ms_per_iteration": 1.5, "iterations_per_s": 666.0, "device_step_ms": 1.2,
+                          "device_idle_frac": 0.2, "host_batch_build_ms": 5.0,
+                          "ms_per_iteration_by_builder_threads": {"0": 6.0, "8": 1.5}, "sampler": "s" * 100}}
     line = json.dumps(bench.compact_line(out), separators=(",", ":"))
     assert len(line) < 6000, len(line)
     assert out["cpu_baseline_reference_code"]["kind"] == "reference-code-over-torch-shim"

@@ -173,3 +173,68 @@ def test_rank_argument_checks(native):
         assert (filt >= 1).all()
     finally:
         eng.close()
+
+
+def test_ranks_at_baseline_scale_equal_the_reference_scorer(native):
+    """tests/golden/reference_ranks_fullscale.npz: the REFERENCE'S OWN Scorer (common/evaluation.py, run by
+    tests/golden/make_reference_rank_fixture.py) ranked 1,200 real FB15k-237 triples on both sides against all 14,541
+    entities, raw and filtered, on DistMult scores of a seeded code / relation table.  Here the same tables go into the
+    engine (a one-layer chain on an empty graph whose codes ARE the table, exactly), this package's Scorer drives
+    rgcn_rank_device with the reference's filter lists, and the 2 x 2,400 ranks must come out the same -- up to the one
+    place two fp32 GEMMs may legitimately disagree, a near-tie with the gold entity (|rank difference| <= 2 on under
+    1 % of the queries; everything else identical), MRR to 1e-6."""
+    import os
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    try:
+        import make_reference_rank_fixture as fx
+    finally:
+        sys.path.remove(golden)
+    from relationprediction_amd.common import evaluation
+    with np.load(os.path.join(golden, "reference_ranks_fullscale.npz")) as z:
+        want_raw, want_filt = z["raw_ranks"], z["filtered_ranks"]
+        assert list(z["config"]) == [fx.V, fx.R, fx.HALF, fx.SEED, fx.NQ]
+        want_mrr = (float(z["mrr_raw"]), float(z["mrr_filtered"]))
+    codes, rel = fx.tables()
+    train, valid, test = fx.splits()
+    V, R, d = fx.V, fx.R, 2 * fx.HALF
+    c = codes[:, :fx.HALF]
+    eye = np.eye(fx.HALF, dtype=np.float32)
+    w_self = np.zeros((d, d), dtype=np.float32)
+    w_self[:fx.HALF, :fx.HALF] = eye
+    w_self[fx.HALF:, :fx.HALF] = -eye
+    w_rel = np.zeros((V, d), dtype=np.float32)
+    w_rel[:R] = rel
+    eng = native.Engine(V, R, d, 1, "block", d // 4, max_edges=1)
+    try:
+        params = {"W_emb": np.concatenate([np.maximum(c, 0), np.maximum(-c, 0)], axis=1), "b_emb": np.zeros(d, np.float32),
+                  "W_f1": np.zeros((R, d // 4, 4, 4), np.float32), "W_b1": np.zeros((R, d // 4, 4, 4), np.float32),
+                  "W_self1": w_self, "b1": np.zeros(d, np.float32), "W_relation": w_rel}
+        eng.set_params(params)
+        eng.set_graph(np.zeros((0, 3), dtype=np.int32))
+        eng.forward(train=False)
+        assert np.array_equal(eng.codes(), codes)                 # the table, bit for bit
+
+        class EngineModel(object):                                # what Scorer asks of a model on the device path
+            test_graph = None
+
+            def device_ranks(self, graph, triples, predict_object, ptr, idx):
+                return eng.ranks(np.ascontiguousarray(triples, dtype=np.int32), predict_object, ptr, idx)
+        eng.rank_reserve(1000)
+        scorer = evaluation.Scorer({"Metric": "MRR"})
+        for part in (train, valid, test):
+            scorer.register_data(part)
+        scorer.register_degrees(train)
+        scorer.register_model(EngineModel())
+        scorer.finalize_frequency_computation(np.concatenate((train, valid, test), axis=0))
+        score = scorer.compute_scores(test, verbose=False)
+        raw, filt = np.asarray(score.raw_ranks), np.asarray(score.filtered_ranks)
+        assert raw.shape == want_raw.shape == (2 * fx.NQ,)
+        for got, want in ((raw, want_raw), (filt, want_filt)):
+            assert np.mean(got != want) < 0.01 and np.abs(got - want).max() <= 2, (np.mean(got != want), np.abs(got - want).max())
+        summary = score.get_summary()
+        assert summary.results['Raw'][summary.mrr_string()] == pytest.approx(want_mrr[0], abs=1e-6)
+        assert summary.results['Filtered'][summary.mrr_string()] == pytest.approx(want_mrr[1], abs=1e-6)
+    finally:
+        eng.close()
