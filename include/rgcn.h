@@ -253,7 +253,10 @@ rgcn_status rgcn_optimizer_step(rgcn_ctx* ctx);
  * RGCN_BUF_NORM_EXCHANGE; the caller sum-all-reduces it (rgcn_optimizer_step does, with RCCL); _apply clips by
  * the global norm and runs Adam.  Replicated tensors receive identical updates on every rank; a relation's
  * weights are current on its owner only, so the owner map must stay fixed over a sharded training run.  The
- * decoder pass (rgcn_decoder_loss_backward_device) is replicated: same batch, same result on every rank. */
+ * stand-alone decoder pass (rgcn_decoder_loss_backward_device) is replicated: same batch, same result on every rank;
+ * inside rgcn_train_step_device / rgcn_train_step_minibatch_device on a context with a communicator the decoder is
+ * DIVIDED by triples: rank g scores the slice [g ceil(N / world), ...) of the batch, and the partial loss, dL/dcodes
+ * and dL/dW_relation are summed over the ranks (three all-reduces: [V,d], [R,d], one float). */
 rgcn_status rgcn_optimizer_norm_partial(rgcn_ctx* ctx);
 rgcn_status rgcn_optimizer_apply(rgcn_ctx* ctx);
 /* One TensorflowOptimizer.update_from_batch (optimize.py:81-88) entirely on the device, asynchronous:

@@ -167,8 +167,10 @@ __global__ void k_negative_sample(const int32_t* __restrict__ batch, int n, int 
 template <int VEC>
 __global__ void __launch_bounds__(256) k_dec_energy(const float* __restrict__ codes, const float* __restrict__ Wr,
                                                     const int32_t* __restrict__ X, const float* __restrict__ Y,
-                                                    int N, int V, int R, int d, float* __restrict__ dx,
+                                                    int N, int Nt, int V, int R, int d, float* __restrict__ dx,
                                                     float* __restrict__ part /* [gridDim.x][2] */) {
+  // N = triples of this launch; Nt = triples of the whole batch (the mean's denominator: a relation-sharded run cuts
+  // the batch into per-rank slices and adds the partial results up)
   __shared__ float red[4][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VEC;
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256) k_dec_energy(const float* __restrict__ co
       const float ax = fabsf(x);
       const float ex = __expf(-ax);
       const float sig = x >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
-      dx[n] = ok ? (sig - y) / (float)N : 0.f;
+      dx[n] = ok ? (sig - y) / (float)Nt : 0.f;
       if (ok) {
         xent += (1.0f - y) * x + log1pf(ex) + fmaxf(-x, 0.f);
         sq += q;
@@ -569,6 +571,9 @@ __global__ void k_dec_rel_reduce(const float* __restrict__ slab, const int32_t* 
   gWr[i] = fmaf(k * cnt, Wr[i], (a0 + a1) + (a2 + a3));
 }
 
+__global__ void k_loss_narrow(const double* __restrict__ loss, float* __restrict__ f) { f[0] = (float)loss[0]; }
+__global__ void k_loss_widen(const float* __restrict__ f, double* __restrict__ loss) { loss[0] = (double)f[0]; }
+
 int bits_for(uint32_t max_value) {
   int b = 1;
   while (b < 32 && (1ull << b) <= max_value) ++b;
@@ -643,11 +648,12 @@ void decoder_free(rgcn_ctx* c) {
 }
 
 // CSR of the decoder batch (depends on X only).  Runs on whatever stream is current.
-rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
+rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t N_total) {
   DecoderBufs& q = c->dec;
   const int N = (int)N64, V = c->V, R = c->R;
   if (N64 > q.maxN) RGCN_FAIL(c, RGCN_ERR_INVALID, "decoder batch larger than rgcn_decoder_reserve'd");
   q.N = N;
+  q.N_total = N_total > 0 ? N_total : N64;
   q.X = X;
   RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, 2 * sizeof(int32_t), c->stream));
   const int T = 256;
@@ -682,11 +688,12 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64) {
 rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, float reg_param) {
   DecoderBufs& q = c->dec;
   const int N = q.N, V = c->V, R = c->R, d = c->d;
+  const int Nt = q.N_total > 0 ? (int)q.N_total : N;      // denominator of the batch mean
   const float* Wr = c->w_rel;
   float* gWr = c->g_rel;
-  if (N <= 0) RGCN_FAIL(c, RGCN_ERR_INVALID, "empty decoder batch");
+  if (N < 0 || (N == 0 && q.N_total <= 0)) RGCN_FAIL(c, RGCN_ERR_INVALID, "empty decoder batch");
   const bool vec4 = (d % 4 == 0) && aligned16(codes) && aligned16(Wr) && aligned16(c->dcodes_own) && aligned16(q.slab);
-  const double Nd = (double)N * d;
+  const double Nd = (double)Nt * d;
   const float k = (float)(2.0 * reg_param / Nd);
   // energies + loss terms (+ the relation gradient's chunk partials when the rows fit a wave's registers)
   static const int fused_env = getenv("RGCN_DEC_FUSED") ? atoi(getenv("RGCN_DEC_FUSED")) : 1;
@@ -701,24 +708,24 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
                  4.0 * d * ((double)V + R) + 20.0 * N + 4.0 * q.max_chunks * d);
 #define RGCN_LAUNCH_ER(VEC, TT)                                                                                    \
   hipLaunchKernelGGL((k_dec_energy_rel<VEC, TT>), dim3(q.max_chunks), dim3(256), lds, c->stream, codes, Wr, q.X, Y, \
-                     q.permr, q.rel_ptr, q.chunk_ptr, N, R, d, q.dx, q.loss_part, q.slab)
+                     q.permr, q.rel_ptr, q.chunk_ptr, Nt, R, d, q.dx, q.loss_part, q.slab)
     if (vec4) {
       if (T == 1) RGCN_LAUNCH_ER(4, 1); else if (T == 2) RGCN_LAUNCH_ER(4, 2); else RGCN_LAUNCH_ER(4, 4);
     } else {
       if (T == 1) RGCN_LAUNCH_ER(1, 1); else if (T == 2) RGCN_LAUNCH_ER(1, 2); else RGCN_LAUNCH_ER(1, 4);
     }
 #undef RGCN_LAUNCH_ER
-    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.max_chunks, N, d, reg_param,
+    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.max_chunks, Nt, d, reg_param,
                        q.loss);
   } else {
     ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d, 4.0 * d * ((double)V + R) + 20.0 * N);
     if (vec4)
-      hipLaunchKernelGGL((k_dec_energy<4>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
+      hipLaunchKernelGGL((k_dec_energy<4>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, Nt, V,
                          R, d, q.dx, q.loss_part);
     else
-      hipLaunchKernelGGL((k_dec_energy<1>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, V,
+      hipLaunchKernelGGL((k_dec_energy<1>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, Nt, V,
                          R, d, q.dx, q.loss_part);
-    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.energy_blocks, N, d, reg_param,
+    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.energy_blocks, Nt, d, reg_param,
                        q.loss);
   }
   {
@@ -766,6 +773,21 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     hipLaunchKernelGGL(k_dec_rel_reduce, dim3((R * d + 255) / 256), dim3(256), 0, c->stream, q.slab, q.chunk_ptr,
                        q.rel_ptr, Wr, gWr, R, d, k);
   }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+// Relation-sharded train step: every rank ran the decoder on ITS slice of the batch's triples (means normalised by the
+// whole batch's size), so dL/dcodes, dL/dW_relation and the loss are partial sums: three all-reduces ([V,d], [R,d], one
+// float).  The reference has no counterpart (single device); DistMult's loss and both gradients are sums over triples
+// (bilinear_diag.py:27-34,63-69), which is what makes the split exact up to summation order.
+rgcn_status decoder_allreduce(rgcn_ctx* c) {
+  DecoderBufs& q = c->dec;
+  RGCN_TRY(comm_allreduce(c, c->dcodes_own, (int64_t)c->V * c->d));
+  RGCN_TRY(comm_allreduce(c, c->g_rel, (int64_t)c->R * c->d));
+  hipLaunchKernelGGL(k_loss_narrow, dim3(1), dim3(1), 0, c->stream, q.loss, q.loss_part);
+  RGCN_TRY(comm_allreduce(c, q.loss_part, 1));
+  hipLaunchKernelGGL(k_loss_widen, dim3(1), dim3(1), 0, c->stream, q.loss_part, q.loss);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

@@ -1133,6 +1133,15 @@ rgcn_status rgcn_optimizer_apply(rgcn_ctx* c) { RGCN_NEED(c); return optimizer_a
 static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const float* Y_dev, int64_t N, uint64_t seed,
                                    float reg_param) {
   RGCN_TRY(forward_all(c, 1, seed, nullptr));
+  // Relation-sharded run: the decoder is divided by TRIPLES -- rank g takes the slice [g ceil(N / world), ...) of the
+  // batch (the codes are replicated after the last forward exchange), its loss terms and gradients are normalised by
+  // the whole batch's N, and the partial dL/dcodes [V,d], dL/dW_relation [R,d] and loss are summed over the ranks
+  // (decoder_allreduce) before the backward pass starts.
+  const int64_t per = (N + c->world - 1) / c->world;
+  const int64_t lo = c->world > 1 ? std::min<int64_t>(N, (int64_t)c->rank * per) : 0;
+  const int64_t n_loc = c->world > 1 ? std::min<int64_t>(N, lo + per) - lo : N;
+  const int32_t* X_loc = X_dev + 3 * lo;
+  const float* Y_loc = Y_dev + lo;
   // The decoder batch's CSRs depend on X only.  They are built on side stream 1, forked at the START of the step,
   // but enqueued AFTER the encoder's prep and forward: their two sorts are ~45 launches of a few microseconds, and
   // queued first they kept the host from feeding the main stream for the first 0.3 ms of every step.
@@ -1143,7 +1152,7 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
   if (c->use_aux || fork_in_capture) {
     RGCN_HIP(c, hipStreamWaitEvent(c->aux[1], c->ev_step_begin, 0));
     c->stream = c->aux[1];
-    const rgcn_status ps = decoder_prepare(c, X_dev, N);
+    const rgcn_status ps = decoder_prepare(c, X_loc, n_loc, N);
     c->stream = c->main_stream;
     RGCN_TRY(ps);
     if (fork_in_capture) {       // (stream_join is a no-op while the side streams are switched off)
@@ -1151,10 +1160,14 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
       RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[1], 0));
     }
   } else {
-    RGCN_TRY(decoder_prepare(c, X_dev, N));
+    RGCN_TRY(decoder_prepare(c, X_loc, n_loc, N));
   }
   RGCN_TRY(stream_join(c, 1));
-  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_dev, reg_param));
+  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_loc, reg_param));
+  if (c->world > 1) {
+    RGCN_TRY(stream_join(c, 2));    // the relation gradient's reduce ran on its own side stream: it is all-reduced too
+    RGCN_TRY(decoder_allreduce(c));
+  }
   c->dec.loss_valid = true;
   RGCN_TRY(backward_all(c, c->dcodes_own));
   RGCN_TRY(stream_join(c, 2));      // dL/dW_relation, computed beside the backward pass

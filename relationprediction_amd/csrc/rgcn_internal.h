@@ -200,6 +200,7 @@ struct GraphBufs {
 struct DecoderBufs {
   int64_t maxN = 0;
   int32_t N = 0;
+  int64_t N_total = 0;         // triples of the whole batch when N is one rank's slice of it (denominator of the means)
   const int32_t* X = nullptr;
   uint32_t *keyv = nullptr, *keyv_s = nullptr, *keyr = nullptr, *keyr_s = nullptr;
   int32_t *valv = nullptr, *permv = nullptr, *valr = nullptr, *permr = nullptr;
@@ -457,8 +458,10 @@ rgcn_status negative_sample(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, in
                             float* Y);
 rgcn_status decoder_reserve(rgcn_ctx* c, int64_t max_triples);
 void decoder_free(rgcn_ctx* c);
-rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N);
+// N_total > N: X_dev is one rank's slice of a batch of N_total triples (relation-sharded train step); 0: N
+rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N, int64_t N_total = 0);
 rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param);
+rgcn_status decoder_allreduce(rgcn_ctx* c);      // sharded run: sum the per-rank partial decoder results
 rgcn_status optimizer_step(rgcn_ctx* c);
 rgcn_status optimizer_norm_partial(rgcn_ctx* c);
 rgcn_status optimizer_apply(rgcn_ctx* c);
