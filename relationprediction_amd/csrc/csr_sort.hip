@@ -12,7 +12,10 @@
 //   k_sort_hist     block b counts the digit values of its 2048 items in LDS  -> table[b][256]          (u16)
 //   k_sort_scatter  block b: digit base = exclusive scan over digits of the table's column sums, plus the column
 //                   prefix over the blocks before b (every block reads the whole table: 512 bytes per block of input,
-//                   cheaper than a scan launch); stable rank inside the block without sorting anything:
+//                   cheaper than a scan launch -- up to kPrefixBlocks blocks, i.e. 524,288 items; beyond that the table
+//                   traffic would grow quadratically (50 GB per pass at 20 M items), so k_sort_prefix first turns the
+//                   table into per-block column prefixes, 256 blocks per workgroup, and a block reads its own row plus
+//                   one total row per 256 blocks); stable rank inside the block without sorting anything:
 //                     - lane rank among the lower lanes of the wave with the same digit: 8 ballots,
 //                     - the 32 wave-rounds of the block (2 rounds x 16 waves, in item order) leave their per-digit
 //                       counts in an LDS table [32][256] (u8), prefixed per digit;
@@ -27,6 +30,7 @@ namespace {
 constexpr int kSortThreads = 1024;
 constexpr int kSortItems = 2048;     // per block: 2 rounds of 1024
 constexpr int kRounds = (kSortItems / kSortThreads) * (kSortThreads / 64);   // wave-rounds per block: 32
+constexpr int kPrefixBlocks = 256;   // blocks per prefix group; sorts of more blocks than this run k_sort_prefix
 
 struct SortJob {
   const uint32_t* key_in;
@@ -35,6 +39,8 @@ struct SortJob {
   int32_t* val_out;
   int32_t* pos_out;           // optional inverse permutation, written by this pass
   uint16_t* table;            // [nblocks][256]
+  uint32_t* before;           // large sorts: [nblocks][256] column prefix inside the block's group of kPrefixBlocks blocks
+  uint32_t* group_total;      // large sorts: [ngroups][256] column sums of every group
   int32_t n;
   int32_t shift;
 };
@@ -58,6 +64,21 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_hist(SortJobs jobs) {
   if (threadIdx.x < 256) job.table[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)hist[threadIdx.x];
 }
 
+// large sorts only: group g = blocks [256 g, 256 g + 256); thread d walks the group's column d
+__global__ void __launch_bounds__(256) k_sort_prefix(SortJobs jobs) {
+  const SortJob job = jobs.j[blockIdx.y];
+  const int nblocks = (job.n + kSortItems - 1) / kSortItems;
+  const int b0 = blockIdx.x * kPrefixBlocks;
+  if (job.before == nullptr || b0 >= nblocks) return;
+  const int b1 = min(nblocks, b0 + kPrefixBlocks), d = threadIdx.x;
+  uint32_t run = 0;
+  for (int b = b0; b < b1; ++b) {
+    job.before[(size_t)b * 256 + d] = run;
+    run += job.table[(size_t)b * 256 + d];
+  }
+  job.group_total[(size_t)blockIdx.x * 256 + d] = run;
+}
+
 __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(SortJobs jobs) {
   const SortJob job = jobs.j[blockIdx.y];
   const int base = blockIdx.x * kSortItems;
@@ -73,10 +94,20 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(SortJobs jobs) {
   {
     const int d = tid & 255, part = tid >> 8;
     uint32_t tot = 0, bef = 0;
-    for (int b = part; b < nblocks; b += 4) {
-      const uint32_t v = job.table[(size_t)b * 256 + d];
-      tot += v;
-      bef += b < (int)blockIdx.x ? v : 0u;
+    if (job.before == nullptr) {
+      for (int b = part; b < nblocks; b += 4) {
+        const uint32_t v = job.table[(size_t)b * 256 + d];
+        tot += v;
+        bef += b < (int)blockIdx.x ? v : 0u;
+      }
+    } else {
+      const int ngroups = (nblocks + kPrefixBlocks - 1) / kPrefixBlocks, mine = (int)blockIdx.x / kPrefixBlocks;
+      for (int g = part; g < ngroups; g += 4) {
+        const uint32_t v = job.group_total[(size_t)g * 256 + d];
+        tot += v;
+        bef += g < mine ? v : 0u;
+      }
+      if (part == 0) bef += job.before[(size_t)blockIdx.x * 256 + d];
     }
     part_total[part][d] = tot;
     part_before[part][d] = bef;
@@ -155,7 +186,14 @@ int passes_for(uint32_t max_key) {
 
 }  // namespace
 
-size_t sort_table_elems(size_t n) { return ((n + kSortItems - 1) / kSortItems + 1) * 256; }
+// uint16 elements: the [nblocks][256] count table, and for large sorts behind it the uint32 prefix rows [nblocks][256]
+// and group totals [ngroups][256]
+size_t sort_table_elems(size_t n) {
+  const size_t nblocks = (n + kSortItems - 1) / kSortItems + 1;
+  size_t elems = nblocks * 256;
+  if (nblocks > (size_t)kPrefixBlocks) elems += 2 * (nblocks + nblocks / kPrefixBlocks + 2) * 256;
+  return elems;
+}
 
 // Stable sort of up to two independent (key, position) arrays by key, on the context's current stream.
 // keys < 2^24 (max_key bounds the passes); key_tmp / val_tmp: scratch of n elements; the result lands in key_out /
@@ -176,10 +214,11 @@ rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* 
   ProfScope ps(c, tag, bytes, 0);
   for (int p = 0; p < max_passes; ++p) {
     SortJobs jobs;
+    bool large = false;
     for (int k = 0; k < 2; ++k) {
       SortJob& j = jobs.j[k];
       if (k >= njobs || p >= passes[k]) {      // nothing (left) to do for this job: an empty job returns at once
-        j = SortJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        j = SortJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
         continue;
       }
       const SortSpec& s = specs[k];
@@ -191,10 +230,21 @@ rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* 
       j.val_out = to_out ? s.val_out : s.val_tmp;
       j.pos_out = p == passes[k] - 1 ? s.pos_out : nullptr;
       j.table = s.table;
+      const size_t nbk = (size_t)((s.n + kSortItems - 1) / kSortItems);
+      j.before = nullptr;
+      j.group_total = nullptr;
+      if (nbk > (size_t)kPrefixBlocks) {
+        j.before = reinterpret_cast<uint32_t*>(s.table + (nbk + 1) * 256);
+        j.group_total = j.before + (nbk + 1) * 256;
+        large = true;
+      }
       j.n = (int32_t)s.n;
       j.shift = 8 * p;
     }
     hipLaunchKernelGGL(k_sort_hist, dim3(max_blocks, njobs), dim3(kSortThreads), 0, c->stream, jobs);
+    if (large)
+      hipLaunchKernelGGL(k_sort_prefix, dim3((max_blocks + kPrefixBlocks - 1) / kPrefixBlocks, njobs), dim3(256), 0,
+                         c->stream, jobs);
     hipLaunchKernelGGL(k_sort_scatter, dim3(max_blocks, njobs), dim3(kSortThreads), 0, c->stream, jobs);
   }
   RGCN_HIP(c, hipGetLastError());

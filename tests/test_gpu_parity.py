@@ -155,11 +155,12 @@ def test_graph_prep_degrees_and_csr(native):
 
 
 @pytest.mark.parametrize("V,R,E", [(97, 5, 400), (14541, 237, 15000), (40943, 18, 10000), (300, 1345, 2049),
-                                   (70000, 3, 5000), (14541, 237, 38001)])
+                                   (70000, 3, 5000), (14541, 237, 38001), (90000, 40, 700000)])
 def test_graph_prep_orderings_equal_a_stable_sort(native, V, R, E):
     """the library's own sort (csr_sort.hip) against numpy's stable argsort: incidences by vertex and messages by
     directed relation, ties in index order -- bit-exact (integer work), incl. more than one 2048-item block, a key
-    range above 16 bits (three radix passes) and hub rows"""
+    range above 16 bits (three radix passes), hub rows, and 1.4 M items (684 blocks: the column-prefix pass of large
+    sorts, k_sort_prefix)"""
     rng = np.random.RandomState(V + E)
     hub = rng.randint(0, V, 8)
     s = np.where(rng.rand(E) < 0.2, hub[rng.randint(0, 8, E)], rng.randint(0, V, E))
