@@ -12,7 +12,7 @@
 //   k_sort_hist     block b counts the digit values of its 2048 items in LDS  -> table[b][256]          (u16)
 //   k_sort_scatter  block b: digit base = exclusive scan over digits of the table's column sums, plus the column
 //                   prefix over the blocks before b (every block reads the whole table: 512 bytes per block of input,
-//                   cheaper than a scan launch -- up to kPrefixBlocks blocks, i.e. 524,288 items; beyond that the table
+//                   cheaper than a scan launch -- up to kPrefixMinBlocks blocks, i.e. 1,048,576 items; beyond that the table
 //                   traffic would grow quadratically (50 GB per pass at 20 M items), so k_sort_prefix first turns the
 //                   table into per-block column prefixes, 256 blocks per workgroup, and a block reads its own row plus
 //                   one total row per 256 blocks); stable rank inside the block without sorting anything:
@@ -30,7 +30,9 @@ namespace {
 constexpr int kSortThreads = 1024;
 constexpr int kSortItems = 2048;     // per block: 2 rounds of 1024
 constexpr int kRounds = (kSortItems / kSortThreads) * (kSortThreads / 64);   // wave-rounds per block: 32
-constexpr int kPrefixBlocks = 256;   // blocks per prefix group; sorts of more blocks than this run k_sort_prefix
+constexpr int kPrefixBlocks = 256;   // blocks per prefix group
+constexpr int kPrefixMinBlocks = 512; // sorts of more blocks than this (1 M items) run k_sort_prefix: below, reading the
+                                      // whole L2-resident table per block (<= 134 MB per pass) is cheaper than one more launch
 
 struct SortJob {
   const uint32_t* key_in;
@@ -191,7 +193,7 @@ int passes_for(uint32_t max_key) {
 size_t sort_table_elems(size_t n) {
   const size_t nblocks = (n + kSortItems - 1) / kSortItems + 1;
   size_t elems = nblocks * 256;
-  if (nblocks > (size_t)kPrefixBlocks) elems += 2 * (nblocks + nblocks / kPrefixBlocks + 2) * 256;
+  if (nblocks > (size_t)kPrefixMinBlocks) elems += 2 * (nblocks + nblocks / kPrefixBlocks + 2) * 256;
   return elems;
 }
 
@@ -233,7 +235,7 @@ rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* 
       const size_t nbk = (size_t)((s.n + kSortItems - 1) / kSortItems);
       j.before = nullptr;
       j.group_total = nullptr;
-      if (nbk > (size_t)kPrefixBlocks) {
+      if (nbk > (size_t)kPrefixMinBlocks) {
         j.before = reinterpret_cast<uint32_t*>(s.table + (nbk + 1) * 256);
         j.group_total = j.before + (nbk + 1) * 256;
         large = true;

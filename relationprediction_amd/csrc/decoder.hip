@@ -254,9 +254,23 @@ struct EntArgs {
   const int32_t* piece_k;
   float* piece_slab;
   float* dcodes;
+  float* dcodes_drop;       // optional: dcodes * dropout of the encoder's top layer (what its self-loop GEMMs consume):
+  DropSpec drop;            // saves the encoder's own scale-and-copy pass over [V,d] (top_grad_dropout) in a train step
   int32_t V, d;
   float k;                  // 2 lambda / (N d)
 };
+
+template <int VEC>
+__device__ __forceinline__ void store_dcodes(const EntArgs& a, size_t off, const float (&acc)[VEC]) {
+#pragma clang fp contract(off)
+  vstore<VEC>(a.dcodes + off, acc);
+  if (a.dcodes_drop != nullptr) {
+    float o2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o2[k] = acc[k] * drop_factor(a.drop, off + k);
+    vstore<VEC>(a.dcodes_drop + off, o2);
+  }
+}
 
 template <int VEC>
 __device__ __forceinline__ void ent_range(const EntArgs& a, int s0, int s1, int step, int cidx, float (&acc)[VEC]) {
@@ -354,7 +368,7 @@ __global__ void __launch_bounds__(kEntThreads) k_dec_entity_grad(EntArgs a, int 
     const float kc = a.k * (float)(end - beg);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = fmaf(kc, self[k], acc[k]);
-    vstore<VEC>(a.dcodes + off, acc);
+    store_dcodes<VEC>(a, off, acc);
   }
 }
 
@@ -379,7 +393,7 @@ __global__ void __launch_bounds__(256) k_dec_long_finish(EntArgs a) {
       vload<VEC>(a.codes + off, self);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] = fmaf(kc, self[k], acc[k]);
-      vstore<VEC>(a.dcodes + off, acc);
+      store_dcodes<VEC>(a, off, acc);
     }
   }
 }
@@ -685,14 +699,16 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t 
 }
 
 // loss + gradients w.r.t. the codes (-> c->dcodes_own) and W_relation (-> its grad buffer)
-rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, float reg_param) {
+rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, float reg_param, float* dcodes_drop,
+                            const DropSpec* drop) {
   DecoderBufs& q = c->dec;
   const int N = q.N, V = c->V, R = c->R, d = c->d;
   const int Nt = q.N_total > 0 ? (int)q.N_total : N;      // denominator of the batch mean
   const float* Wr = c->w_rel;
   float* gWr = c->g_rel;
   if (N < 0 || (N == 0 && q.N_total <= 0)) RGCN_FAIL(c, RGCN_ERR_INVALID, "empty decoder batch");
-  const bool vec4 = (d % 4 == 0) && aligned16(codes) && aligned16(Wr) && aligned16(c->dcodes_own) && aligned16(q.slab);
+  const bool vec4 = (d % 4 == 0) && aligned16(codes) && aligned16(Wr) && aligned16(c->dcodes_own) && aligned16(q.slab) &&
+                    aligned16(dcodes_drop);
   const double Nd = (double)Nt * d;
   const float k = (float)(2.0 * reg_param / Nd);
   // energies + loss terms (+ the relation gradient's chunk partials when the rows fit a wave's registers)
@@ -735,6 +751,8 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     a.long_first = q.long_first; a.long_cnt = q.long_cnt; a.piece_row = q.piece_row; a.piece_k = q.piece_k;
     a.piece_slab = q.piece_slab;
     a.k = k;
+    a.dcodes_drop = (dcodes_drop != nullptr && drop != nullptr && drop->mode != DROP_NONE) ? dcodes_drop : nullptr;
+    if (drop != nullptr) a.drop = *drop; else a.drop = DropSpec{DROP_NONE, 0, 0, 1.0f, 0, nullptr, nullptr};
     const int nvec = vec4 ? d / 4 : d;
     const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
     const int rpb = kEntThreads / tpr;

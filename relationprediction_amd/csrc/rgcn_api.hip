@@ -630,13 +630,17 @@ static rgcn_status fwd_layer_finish(rgcn_ctx* c, int l) {
 }
 
 // ---------------------------------------------------------------- backward
-static rgcn_status bwd_begin(rgcn_ctx* c, const float* dcodes_dev) {
+// ds_ready: dcodes * dropout of the top layer, already written by the producer of dcodes (the device decoder does,
+// inside a train step): the scale-and-copy pass over [V,d] is skipped
+static rgcn_status bwd_begin(rgcn_ctx* c, const float* dcodes_dev, const float* ds_ready = nullptr) {
   if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward needs a completed rgcn_forward on the current graph");
   if (!dcodes_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "dcodes is NULL");
   c->bwd_layer = c->L;
   c->bwd_D = dcodes_dev;
   DropSpec ds = make_drop(c, c->L, true);
-  if (ds.mode != DROP_NONE) {
+  if (ds.mode != DROP_NONE && ds_ready != nullptr) {
+    c->bwd_dS = ds_ready;
+  } else if (ds.mode != DROP_NONE) {
     RGCN_TRY(scale_dropout(c, dcodes_dev, c->dsbuf[c->L & 1], ds));
     c->bwd_dS = c->dsbuf[c->L & 1];
   } else {
@@ -844,10 +848,10 @@ static rgcn_status forward_all(rgcn_ctx* c, int train, uint64_t seed, const uint
   return RGCN_OK;
 }
 
-static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev) {
+static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev, const float* ds_ready = nullptr) {
   if (c->world > 1 && !c->comm)
     RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
-  RGCN_TRY(bwd_begin(c, dcodes_dev));
+  RGCN_TRY(bwd_begin(c, dcodes_dev, ds_ready));
   for (int l = c->L; l >= 1; --l) {
     RGCN_TRY(bwd_layer_partial(c, l));
     if (c->world > 1) RGCN_TRY(bwd_exchange(c, l));
@@ -1163,13 +1167,17 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
     RGCN_TRY(decoder_prepare(c, X_loc, n_loc, N));
   }
   RGCN_TRY(stream_join(c, 1));
-  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_loc, reg_param));
+  // one GPU: the decoder's entity-gradient kernel also writes dL/dcodes * dropout_L, the operand of the top layer's
+  // self-loop GEMMs (a sharded run scales after the all-reduce of the partial dL/dcodes, in bwd_begin)
+  const DropSpec top_drop = make_drop(c, c->L, true);
+  float* ds_ready = (c->world == 1 && top_drop.mode != DROP_NONE) ? c->dsbuf[c->L & 1] : nullptr;
+  RGCN_TRY(decoder_compute(c, c->H[c->L], Y_loc, reg_param, ds_ready, &top_drop));
   if (c->world > 1) {
     RGCN_TRY(stream_join(c, 2));    // the relation gradient's reduce ran on its own side stream: it is all-reduced too
     RGCN_TRY(decoder_allreduce(c));
   }
   c->dec.loss_valid = true;
-  RGCN_TRY(backward_all(c, c->dcodes_own));
+  RGCN_TRY(backward_all(c, c->dcodes_own, ds_ready));
   RGCN_TRY(stream_join(c, 2));      // dL/dW_relation, computed beside the backward pass
   RGCN_TRY(step_end(c));
   if (c->opt.configured) RGCN_TRY(optimizer_step(c));

@@ -460,7 +460,9 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t max_triples);
 void decoder_free(rgcn_ctx* c);
 // N_total > N: X_dev is one rank's slice of a batch of N_total triples (relation-sharded train step); 0: N
 rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X_dev, int64_t N, int64_t N_total = 0);
-rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param);
+// dcodes_drop / drop (optional): also write dL/dcodes * drop, the dropout-scaled copy the encoder's top layer consumes
+rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y_dev, float reg_param,
+                            float* dcodes_drop = nullptr, const DropSpec* drop = nullptr);
 rgcn_status decoder_allreduce(rgcn_ctx* c);      // sharded run: sum the per-rank partial decoder results
 rgcn_status optimizer_step(rgcn_ctx* c);
 rgcn_status optimizer_norm_partial(rgcn_ctx* c);
