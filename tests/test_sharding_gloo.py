@@ -86,3 +86,44 @@ def test_sharded_forward_equals_unsharded_gloo(kind, nb):
     assert len(ret) == world
     for rank in range(world):
         assert ret[rank] < 1e-5, ret
+
+
+def _decoder_worker(rank, world, port, ret):
+    """The decoder of a sharded train step (csrc/rgcn_api.hip train_step_tail + decoder_allreduce): rank g scores the
+    slice [g ceil(N / world), ...) of the batch, its loss terms and gradients normalised by the WHOLE batch's N, and the
+    partial loss, dL/dcodes and dL/dW_relation are summed over the ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, R, d, N, reg = 50, 6, 16, 203, 0.01            # N not divisible by the world size
+        rng = np.random.RandomState(9)
+        codes = rng.randn(V, d).astype(np.float32)
+        w_rel = rng.randn(V, d).astype(np.float32)
+        X = np.stack([rng.randint(0, V, N), rng.randint(0, R, N), rng.randint(0, V, N)], 1).astype(np.int32)
+        Y = (rng.rand(N) < 0.1).astype(np.float32)
+        per = (N + world - 1) // world
+        lo, hi = min(N, rank * per), min(N, rank * per + per)
+        n = hi - lo
+        # the oracle normalises by the size of the batch it is given: rescale the slice's means to the whole batch's N
+        loss, dcodes, drel = oracle.distmult_loss_and_grads(codes, w_rel, X[lo:hi], Y[lo:hi], reg)
+        part = [torch.tensor([loss * n / N], dtype=torch.float64), torch.from_numpy(dcodes.astype(np.float64) * n / N),
+                torch.from_numpy(drel.astype(np.float64) * n / N)]
+        for t in part:
+            dist.all_reduce(t)
+        floss, fdcodes, fdrel = oracle.distmult_loss_and_grads(codes, w_rel, X, Y, reg)
+        ret[rank] = (abs(float(part[0]) - floss) / abs(floss), float(np.abs(part[1].numpy() - fdcodes).max()),
+                     float(np.abs(part[2].numpy() - fdrel).max()), float(np.abs(fdcodes).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_decoder_divided_by_triples_equals_the_whole_batch_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_decoder_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        rel_loss, e_codes, e_rel, scale = ret[rank]
+        assert rel_loss < 1e-6 and e_codes < 2e-6 * max(scale, 1.0) and e_rel < 2e-6 * max(scale, 1.0), ret[rank]
