@@ -661,6 +661,8 @@ def measure_train_loop(args, device_step_ms, iterations=150, workers=(0, 8)):
         encoder = model_builder.build_encoder(s['Encoder'], triples)
         model = model_builder.build_decoder(encoder, s['Decoder'])
         t_func = train.make_transform(triples, general, encoder, device_negatives=True, device_dropout=True)
+        t_func_dev = train.make_transform(triples, general, encoder, device_negatives=True, device_dropout=True,
+                                          device_sampler=True)
         model.preprocess(triples)
         model.register_for_test(triples)
         model.initialize_train()
@@ -675,26 +677,34 @@ def measure_train_loop(args, device_step_ms, iterations=150, workers=(0, 8)):
                 ts.append(time.perf_counter() - t0)
             out["host_batch_build_ms"] = round(float(np.median(ts[1:])) * 1e3, 3)
 
-            def fit(n_iter, nworkers):
+            def fit(n_iter, nworkers, transform):
                 s2, _ = build(n_iter)
                 opp = optimizer_parameter_parser.Parser(s2['Optimizer'])
                 opp.set_save_function(lambda p: None)
-                opp.set_sample_transform_function(t_func)
+                opp.set_sample_transform_function(transform)
                 opt = build_hip(model, [p for p in opp.get_parametrization() if p[0] != 'ModelSaver'],
                                 batch_workers=nworkers)
                 np.random.seed(0)
                 t0 = time.perf_counter()
                 n = opt.fit(triples)
                 return (time.perf_counter() - t0) * 1e3 / max(n, 1), n
-            fit(12, 0)                                    # warm-up: lazy allocations, first sampler state
+            fit(12, 0, t_func)                            # warm-up: lazy allocations, first sampler state
             per_worker = {}
             for w in workers:
-                ms, n = fit(iterations, w)
+                ms, n = fit(iterations, w, t_func)
                 per_worker[str(w)] = round(ms, 4)
             out["ms_per_iteration_by_builder_threads"] = per_worker
+            # all three draws on the device (neighbourhood sampler = parallel first-passage percolation, edge dropout,
+            # negatives): no batch is built on the host, nothing is uploaded
+            fit(12, 0, t_func_dev)
+            ms_dev, _ = fit(iterations, 0, t_func_dev)
+            out["ms_per_iteration_device_sampler"] = round(ms_dev, 4)
+            out["sampler"] = ("device (csrc/neighborhood.hip: the reference's process as parallel first-passage "
+                              "percolation) for ms_per_iteration_device_sampler; host O(log V) port with k builder "
+                              "threads for ms_per_iteration_by_builder_threads")
             dev_ms = float(device_step_ms)      # the same device call, launched back to back without host waits (train_steps)
             out["device_step_ms"] = round(dev_ms, 4)
-            best = min(per_worker.values())
+            best = min(min(per_worker.values()), out["ms_per_iteration_device_sampler"])
             out["ms_per_iteration"] = best
             out["iterations_per_s"] = round(1e3 / best, 1)
             out["device_idle_frac"] = round(max(0.0, 1.0 - dev_ms / best), 4)
@@ -827,7 +837,8 @@ def compact_line(out):
                                                "ranked_triples_per_s")} if ev else None)
     tl = out.get("train_loop")
     line["train_loop"] = ({k: tl[k] for k in ("ms_per_iteration", "iterations_per_s", "device_step_ms", "device_idle_frac",
-                                               "host_batch_build_ms", "ms_per_iteration_by_builder_threads")} if tl else None)
+                                               "host_batch_build_ms", "ms_per_iteration_by_builder_threads",
+                                               "ms_per_iteration_device_sampler")} if tl else None)
     line["details"] = out.get("details")
     return line
 

@@ -216,6 +216,25 @@ void rgcn_sampler_destroy(rgcn_sampler* sampler);
 rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* sampler, int64_t sample_size, uint64_t seed,
                                            int32_t* out_edge_ids);
 
+/* The same sampler ON THE DEVICE (csrc/neighborhood.hip): sample_edge_neighborhood's process has the distribution of
+ * first-passage percolation with an Exp(1) clock on every edge end (a touched vertex's free edge ends are equally
+ * likely to be picked next = they race with memoryless clocks), its restart rule that of a uniform random vertex order
+ * over the connected components -- so the batch is every edge of the components visited in full plus the edges of
+ * least pick time of the component the budget runs out in: parallel Bellman-Ford sweeps over the adjacency, a radix
+ * select and a stable compaction on the device, the component order from V hashes on the host inside the call.  Same
+ * distribution as code/train.py:161-198 (held to it by tests/test_gpu_sampler.py), another random stream, a function of
+ * `seed` alone, no batch built on the host and no upload.  rgcn_neighborhood_reserve hands the training graph over once
+ * (code/train.py:133-139 builds the adjacency lists once): ids are validated, components and adjacency are built on
+ * the host and copied; rgcn_sample_neighborhood_device writes the drawn rows int32 [sample_size,3] (in edge order) to
+ * batch_out_dev, asynchronously on the main stream or -- on_prefetch_stream != 0 -- on the stream
+ * rgcn_prefetch_graph*_device works on, so that "draw the next batch, drop edges, prepare its graph" runs beside the
+ * current step.  sample_size above the number of training triples is an error; a graph whose sweeps do not
+ * settle within the budget (shortest paths of more than ~100 hops) is refused at the next synchronising call, never
+ * answered wrongly. */
+rgcn_status rgcn_neighborhood_reserve(rgcn_ctx* ctx, const int32_t* triples_host, int64_t num_triples);
+rgcn_status rgcn_sample_neighborhood_device(rgcn_ctx* ctx, int64_t sample_size, uint64_t seed, int32_t* batch_out_dev,
+                                            int32_t on_prefetch_stream);
+
 /* NegativeSampler.transform (code/common/auxilliaries.py:13-33) on the device: x_out = int32 [n*(rate+1), 3], the batch
  * tiled rate+1 times with, in every row after the first n, the object (fair coin) or else the subject replaced by a
  * uniform entity id; y_out = float32 [n*(rate+1)], 1 for the first n rows, 0 after.  Same layout and distribution as

@@ -73,6 +73,8 @@ _SIGS = {
     "rgcn_sampler_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(_P)]),
     "rgcn_sampler_destroy": (None, [_P]),
     "rgcn_sampler_edge_neighborhood": (C.c_int32, [_P, C.c_int64, C.c_uint64, _P]),
+    "rgcn_neighborhood_reserve": (C.c_int32, [_P, _P, C.c_int64]),
+    "rgcn_sample_neighborhood_device": (C.c_int32, [_P, C.c_int64, C.c_uint64, _P, C.c_int32]),
     "rgcn_capture_begin": (C.c_int32, [_P]),
     "rgcn_capture_end": (C.c_int32, [_P, C.POINTER(C.c_int32)]),
     "rgcn_graph_launch": (C.c_int32, [_P, C.c_int32]),
@@ -456,6 +458,17 @@ class Engine:
 
     def graph_destroy(self, graph_id):
         self._check(self.lib.rgcn_graph_destroy(self.ctx, int(graph_id)))
+
+    def neighborhood_reserve(self, train_triples):
+        """the training graph to the device, once: what rgcn_sample_neighborhood_device draws graph batches from"""
+        t = np.ascontiguousarray(train_triples, dtype=np.int32).reshape(-1, 3)
+        self._check(self.lib.rgcn_neighborhood_reserve(self.ctx, _ptr(t), len(t)))
+        self._nbr_edges = len(t)
+
+    def sample_neighborhood_device(self, sample_size, seed, batch_dev, on_prefetch_stream=False):
+        """sample_edge_neighborhood (code/train.py:161-198) on the device: [sample_size,3] rows into batch_dev"""
+        self._check(self.lib.rgcn_sample_neighborhood_device(self.ctx, int(sample_size), C.c_uint64(int(seed)),
+                                                             batch_dev.ptr, 1 if on_prefetch_stream else 0))
 
     def negative_sample_device(self, batch_dev, n, rate, seed, x_dev, y_dev):
         """X [n*(rate+1),3] and Y [n*(rate+1)] from the batch of n triples, all on the device."""

@@ -25,7 +25,7 @@ LIB = os.path.join(LIBDIR, "librgcn.so")
 LIB_DEVTOOLS = os.path.join(LIBDIR, "librgcn_devtools.so")
 ARCH = "gfx950"
 SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "block_spmm.hip", "basis.hip",
-           "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "comm.hip"]
+           "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "neighborhood.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h"),
            os.path.join(ROOT, "include", "rgcn_devtools.h")]
 DEVTOOLS_SOURCES = ["rgcn_api.hip"]       # the only translation unit the flag changes

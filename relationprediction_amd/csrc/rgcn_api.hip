@@ -151,6 +151,8 @@ static rgcn_status check_dev_flag(rgcn_ctx* c, bool main_only = false) {
   if (flag) {
     RGCN_HIP(c, hipMemsetAsync(c->g.errflag, 0, sizeof(int32_t), c->stream));
     RGCN_FAIL(c, RGCN_ERR_INVALID, std::string(flag & 4 ? "edge dropout: the keep mask does not hold exactly `keep` ones; " : "") +
+                                   (flag & 8 ? "device neighbourhood sampler: the relaxations did not settle within their iteration budget "
+                                               "(a graph of very large diameter: use the host sampler); " : "") +
                                    (flag & 3 ? "graph_edges / the decoder batch contains a vertex id outside [0,EntityCount) or a "
                                                "relation id outside [0,RelationCount)" : ""));
   }
@@ -237,6 +239,7 @@ static void free_all(rgcn_ctx* c) {
   graph_free(c);
   auto F = [](void* p) { if (p) (void)hipFree(p); };
   decoder_free(c);
+  neighborhood_free(c);
   optimizer_free(c);
   rank_free(c);
   if (c->giant_slab) (void)hipFree(c->giant_slab);
@@ -1284,6 +1287,35 @@ rgcn_status rgcn_train_step_minibatch_device(rgcn_ctx* c, const int32_t* batch_d
   // the decoder's batch preparation forks from ev_step_begin onto a side stream: it must see the sampled batch
   RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
   return train_step_tail(c, x_scratch_dev, y_scratch_dev, N, dropout_seed, reg_param);
+}
+
+// ---- neighbourhood edge sampler on the device ------------------------------------------
+rgcn_status rgcn_neighborhood_reserve(rgcn_ctx* c, const int32_t* triples_host, int64_t n) {
+  RGCN_NEED(c);
+  if (n <= 0 || n >= ((int64_t)1 << 31) / 3 || !triples_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "need the training triples");
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "not while a hipGraph is being captured");
+  for (int64_t e = 0; e < n; ++e) {
+    const int32_t s = triples_host[3 * e], r = triples_host[3 * e + 1], o = triples_host[3 * e + 2];
+    if (s < 0 || s >= c->V || o < 0 || o >= c->V || r < 0 || r >= c->R)
+      RGCN_FAIL(c, RGCN_ERR_INVALID, "training triple " + std::to_string(e) + " has an id out of range");
+  }
+  RGCN_TRY(sync_all(c));
+  return neighborhood_reserve(c, triples_host, n);
+}
+
+rgcn_status rgcn_sample_neighborhood_device(rgcn_ctx* c, int64_t sample_size, uint64_t seed, int32_t* batch_out_dev,
+                                            int32_t on_prefetch_stream) {
+  RGCN_NEED(c);
+  if (c->nbr.n <= 0) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_neighborhood_reserve first");
+  // the reference's loop dies on NaN probabilities when asked for more edges than the graph has
+  if (sample_size < 0 || sample_size > c->nbr.n) RGCN_FAIL(c, RGCN_ERR_INVALID, "sample_size outside [0, number of training triples]");
+  if (sample_size > 0 && !batch_out_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "not while a hipGraph is being captured");
+  invalidate_prefetch_of(c, batch_out_dev, sizeof(int32_t) * 3 * (size_t)sample_size);
+  if (on_prefetch_stream) c->stream = c->pf_stream;
+  const rgcn_status s = neighborhood_sample(c, sample_size, seed, batch_out_dev, on_prefetch_stream != 0);
+  c->stream = c->main_stream;
+  return s;
 }
 
 // ---- hipGraph capture of whole steps --------------------------------------------------------------

@@ -219,6 +219,30 @@ struct DecoderBufs {
   bool loss_valid = false;
 };
 
+// device neighbourhood sampler (csrc/neighborhood.hip): the training graph and the scratch of one draw
+struct NeighborhoodBufs {
+  int64_t n = 0;                         // training triples
+  int32_t* triples = nullptr;            // [n,3]
+  // adjacency CSR by vertex, self loops left out: the other endpoint, and the id 2 e + side of the edge END AT THAT
+  // OTHER endpoint (whose clock a relaxation adds)
+  int32_t *adj_other = nullptr, *adj_end = nullptr;
+  int32_t *seg_v = nullptr, *seg_beg = nullptr, *seg_end = nullptr;     // segments of <= 256 entries of one vertex's list
+  int32_t nseg = 0;
+  int32_t* comp = nullptr;               // [V] connected component of the vertex (-1: no edges)
+  uint8_t* comp_state = nullptr;         // [ncomp] 1: every edge of the component is in the batch (device copy)
+  uint32_t* dist = nullptr;              // [V] touched-time (bits of a non-negative float)
+  unsigned long long* tkey = nullptr;    // [n] (pick time | edge id) of the boundary component's edges, ~0 elsewhere
+  uint32_t* hist = nullptr;              // [4096] digit histogram of the radix select
+  unsigned long long* state = nullptr;   // select state (prefix, wanted rank)
+  int32_t* changed = nullptr;            // per-launch "something moved" flags of the relaxation
+  uint32_t* bcnt = nullptr;              // per-block counts / offsets of the compaction
+  // host side (components are a property of the graph: found once, at reserve)
+  std::vector<int32_t> comp_h;           // [V]
+  std::vector<int64_t> comp_edges_h;     // [ncomp] edges per component
+  std::vector<uint8_t> comp_state_h;     // [ncomp] scratch of one draw
+  int32_t ncomp = 0;
+};
+
 struct OptimizerState {
   bool configured = false;
   float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, max_norm = 0.f;
@@ -262,6 +286,7 @@ struct rgcn_ctx {
   float *w_emb = nullptr, *g_emb = nullptr, *b_emb = nullptr, *gb_emb = nullptr;
   float *w_rel = nullptr, *g_rel = nullptr;   // W_relation [EntityCount, d] (decoder weight)
   rgcn::DecoderBufs dec;
+  rgcn::NeighborhoodBufs nbr;
   rgcn::OptimizerState opt;
 
   std::vector<float*> H;                 // H[0..L], [V,d] each
@@ -467,6 +492,11 @@ rgcn_status decoder_allreduce(rgcn_ctx* c);      // sharded run: sum the per-ran
 rgcn_status optimizer_step(rgcn_ctx* c);
 rgcn_status optimizer_norm_partial(rgcn_ctx* c);
 rgcn_status optimizer_apply(rgcn_ctx* c);
+// ---- neighborhood.hip: sample_edge_neighborhood on the device (parallel first-passage percolation)
+rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* triples_host, int64_t n);
+rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t sample_size, uint64_t seed, int32_t* batch_out_dev,
+                                bool on_prefetch_stream);
+void neighborhood_free(rgcn_ctx* c);
 // ---- ranking.hip
 rgcn_status rank_reserve(rgcn_ctx* c, int64_t max_queries);
 void rank_free(rgcn_ctx* c);

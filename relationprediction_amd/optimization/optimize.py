@@ -275,10 +275,15 @@ class DeviceNegatives(object):
 class DeviceMinibatch(object):
     """A processed batch that leaves BOTH random draws of the reference's t_func to the device step: which `keep` of
     the batch's edges the encoder sees (edge dropout, train.py:233-238) and the corruptions (auxilliaries.py:13-33).
-    Only `batch` crosses PCIe (rgcn_train_step_minibatch_device)."""
+    Only `batch` crosses PCIe (rgcn_train_step_minibatch_device).
 
-    def __init__(self, batch, keep, edge_seed, rate):
+    With `sample = (train_triplets, sample_size, sampler_seed)` and `batch = None` the THIRD draw happens on the device
+    too -- the neighbourhood edge sampler (train.py:161-198; rgcn_sample_neighborhood_device): nothing is built on the
+    host and nothing is uploaded, an iteration is three seeds."""
+
+    def __init__(self, batch, keep, edge_seed, rate, sample=None):
         self.batch, self.keep, self.edge_seed, self.rate = batch, int(keep), int(edge_seed), int(rate)
+        self.sample = sample
 
 
 class HipOptimizer(object):

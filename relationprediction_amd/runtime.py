@@ -127,36 +127,62 @@ class EncoderRuntime(object):
             self.engine.copy_to_device_async(bd, b)
         self._staged = (graph_edges, batch, slot, gd, len(g), bd, nb)
 
+    def _sampled_batch(self, mb, slot_name, on_prefetch_stream):
+        """the graph batch of a device-sampled minibatch: drawn into a device buffer by the device sampler"""
+        train, size, seed = mb.sample
+        if getattr(self, "_nbr_graph", None) is not train:
+            self.engine.neighborhood_reserve(train)        # the training graph moves to the device once
+            self._nbr_graph = train
+        bd = self._buffer(slot_name, 12 * int(size))
+        self.engine.sample_neighborhood_device(int(size), int(seed), bd, on_prefetch_stream=on_prefetch_stream)
+        return bd, int(size)
+
     def stage_minibatch(self, mb):
         """The device-dropout flavour of stage(): ONE upload (the graph batch; it is the edge-dropout input and the
         decoder's positives at once) on the prefetch stream, then the draw of the kept edges and the preparation of
-        their graph there, beside the running step (rgcn_prefetch_graph_dropout_device)."""
-        b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
-        if len(b) > self.engine.max_edges:
-            return
+        their graph there, beside the running step (rgcn_prefetch_graph_dropout_device).  A device-sampled minibatch
+        has no upload at all: the batch itself is drawn there first (rgcn_sample_neighborhood_device)."""
         slot = getattr(self, "_slot", 0) ^ 1
-        bd = self._buffer("mbatch%d" % slot, b.nbytes)
-        self.engine.copy_to_device_async(bd, b, on_prefetch_stream=True)
-        self.engine.prefetch_graph_dropout_device(bd, len(b), mb.keep, mb.edge_seed)
-        self._staged = (mb, None, slot, bd, len(b), None, 0)
+        if getattr(mb, "sample", None) is not None:
+            if int(mb.sample[1]) > self.engine.max_edges:
+                return
+            bd, nb = self._sampled_batch(mb, "mbatch%d" % slot, True)
+        else:
+            b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
+            if len(b) > self.engine.max_edges:
+                return
+            bd, nb = self._buffer("mbatch%d" % slot, b.nbytes), len(b)
+            self.engine.copy_to_device_async(bd, b, on_prefetch_stream=True)
+        self.engine.prefetch_graph_dropout_device(bd, nb, mb.keep, mb.edge_seed)
+        self._staged = (mb, None, slot, bd, nb, None, 0)
 
     def train_step_minibatch(self, mb, reg_param, seed):
         """One iteration from a graph batch resident on the device: edge dropout, negative sampling and the train
         step in one asynchronous call (rgcn_train_step_minibatch_device)."""
-        b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
-        n = len(b) * (int(mb.rate) + 1)
+        sampled = getattr(mb, "sample", None) is not None
+        if sampled:
+            nb = int(mb.sample[1])
+        else:
+            b = np.ascontiguousarray(mb.batch, dtype=np.int32).reshape(-1, 3)
+            nb = len(b)
+        n = nb * (int(mb.rate) + 1)
         if n == 0:
             raise ValueError("empty decoder batch")
-        if len(b) > self.engine.max_edges:
+        if nb > self.engine.max_edges:
             raise ValueError("graph batch of %d edges exceeds the context's max_edges %d"
-                             % (len(b), self.engine.max_edges))
+                             % (nb, self.engine.max_edges))
         if n > self._dec_reserved:
             self.engine.decoder_reserve(n)
             self._dec_reserved = n
         st = self._take_staged(mb, None)
-        bd = st[3] if st is not None else self._upload("mbatch", b)
+        if st is not None:
+            bd = st[3]
+        elif sampled:
+            bd, _ = self._sampled_batch(mb, "mbatch", False)
+        else:
+            bd = self._upload("mbatch", b)
         xd, yd = self._buffer("X", 12 * n), self._buffer("Y", 4 * n)
-        self.engine.train_step_minibatch_device(bd, len(b), mb.keep, mb.edge_seed, mb.rate, seed ^ 0x5bd1e995, xd, yd,
+        self.engine.train_step_minibatch_device(bd, nb, mb.keep, mb.edge_seed, mb.rate, seed ^ 0x5bd1e995, xd, yd,
                                                 seed=seed, reg_param=reg_param)
         self._state = None
         self._graph_version = None

@@ -33,7 +33,8 @@ def load_dataset(dataset, metric='MRR'):
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
 
-def make_transform(train_triplets, general_settings, encoder, device_negatives=False, device_dropout=False):
+def make_transform(train_triplets, general_settings, encoder, device_negatives=False, device_dropout=False,
+                   device_sampler=False):
     """The reference's t_func (train.py:201-247): minibatch -> (graph_split, X, Y).
 
     Every batch is a function of ONE seed drawn from numpy's global generator when the batch is requested, so
@@ -50,12 +51,20 @@ def make_transform(train_triplets, general_settings, encoder, device_negatives=F
                          "train on the whole graph, or lower it" % (int(general_settings['GraphBatchSize']),
                                                                     len(train_triplets)))
     local = threading.local()            # the native sampler keeps per-sample state: one per thread
+    train_arr = np.ascontiguousarray(train_triplets, dtype=np.int32)     # (what the device sampler keeps resident)
 
     def seeded(x, seed):
         rng = np.random.RandomState(seed)
         arr = np.asarray(x)
         if not encoder.needs_graph():
             return ns.transform(arr, rng)
+        if use_sampler and device_sampler and device_dropout:
+            # all three draws on the device: the iteration is three seeds, nothing is built on the host or uploaded
+            from .optimization.optimize import DeviceMinibatch
+            size = int(general_settings['GraphBatchSize'])
+            split_size = int(float(general_settings['GraphSplitSize']) * size)
+            sample = (train_arr, size, rng.randint(0, 2 ** 31 - 1))
+            return DeviceMinibatch(None, split_size, rng.randint(0, 2 ** 31 - 1), ns.negative_sample_rate, sample=sample)
         if use_sampler:
             if not hasattr(local, 'sampler'):
                 local.sampler = _native.NeighborhoodSampler(train_triplets, int(general_settings['EntityCount']))
@@ -94,6 +103,9 @@ def main(argv=None):
     parser.add_argument("--host-edge-dropout", action="store_true",
                         help="choose the GraphSplitSize subset of each graph batch with numpy on the host (the "
                              "reference's np.random.choice) instead of on the device")
+    parser.add_argument("--host-sampler", action="store_true",
+                        help="draw the neighbourhood graph batch with the host sampler (librgcn.so's O(log V) port of "
+                             "sample_edge_neighborhood, built ahead by --batch-workers threads) instead of on the device")
     parser.add_argument("--batch-workers", type=int, default=8,
                         help="background threads that build minibatches ahead of the device (0: build in line)")
     args = parser.parse_args(argv)
@@ -151,7 +163,8 @@ def main(argv=None):
         opp.set_sample_transform_function(make_transform(train_triplets, general_settings, encoder,
                                                          device_negatives=not args.host_negatives,
                                                          device_dropout=not (args.host_negatives or
-                                                                             args.host_edge_dropout)))
+                                                                             args.host_edge_dropout),
+                                                         device_sampler=not args.host_sampler))
 
     model.preprocess(train_triplets)
     model.register_for_test(train_triplets)

@@ -151,7 +151,8 @@ def test_bench_result_line_stays_compact_and_self_spawns():
                           "ranked_triples_per_s": 8e5, "note": "n" * 300}, "details": "bench_details.json",
            "train_loop": {"ms_per_iteration": 1.5, "iterations_per_s": 666.0, "device_step_ms": 1.2,
                           "device_idle_frac": 0.2, "host_batch_build_ms": 5.0,
-                          "ms_per_iteration_by_builder_threads": {"0": 6.0, "8": 1.5}, "sampler": "s" * 100}}
+                          "ms_per_iteration_by_builder_threads": {"0": 6.0, "8": 1.5},
+                          "ms_per_iteration_device_sampler": 1.3, "sampler": "s" * 100}}
     line = json.dumps(bench.compact_line(out), separators=(",", ":"))
     assert len(line) < 6000, len(line)
     assert out["cpu_baseline_reference_code"]["kind"] == "reference-code-over-torch-shim"

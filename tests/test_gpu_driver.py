@@ -77,7 +77,10 @@ def write_dataset(root, V=200, R=6, n_train=700, seed=0):
     return triples[:n_train]
 
 
-@pytest.mark.parametrize("concat,nb,extra", [("Yes", 4, []), ("No", 2, []), ("Yes", 4, ["--host-negatives", "--batch-workers", "0"])])
+# default: all three random draws of an iteration on the device (neighbourhood sampler, edge dropout, negatives);
+# --host-sampler: the graph batch from the host port of sample_edge_neighborhood, built ahead by worker threads
+@pytest.mark.parametrize("concat,nb,extra", [("Yes", 4, []), ("No", 2, []), ("Yes", 4, ["--host-negatives", "--batch-workers", "0"]),
+                                             ("Yes", 4, ["--host-sampler"])])
 def test_train_driver_end_to_end(tmp_path, capsys, concat, nb, extra):
     from relationprediction_amd import train
     data = str(tmp_path / "data")

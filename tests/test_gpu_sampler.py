@@ -1,0 +1,174 @@
+"""The neighbourhood edge sampler on the device (include/rgcn.h rgcn_sample_neighborhood_device, csrc/neighborhood.hip)
+against the reference's process (code/train.py:161-198, restated step for step in oracle.sample_edge_neighborhood and
+held draw for draw to the reference's own function by tests/test_reference_fixtures.py).  The device algorithm is a
+parallel one (first-passage percolation with Exp(1) clocks on the edge ends + a uniform vertex order over the
+components), another random stream with the SAME distribution: the tests compare distributions, and the invariants."""
+import collections
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from relationprediction_amd import _native
+    _native.load_library()
+    return _native
+
+
+def draw(native, eng, buf, k, seed):
+    eng.sample_neighborhood_device(k, seed, buf)
+    return buf.download(np.int32, (k, 3))
+
+
+def outcome(rows):
+    """the drawn set as a multiset of rows (parallel edges have equal rows: which of them was drawn cannot be told
+    from the batch, nor does it matter to anything downstream)"""
+    return tuple(sorted(map(tuple, np.asarray(rows).tolist())))
+
+
+def rows_to_ids(triples, rows):
+    """edge ids of the drawn rows (rows come in edge order; parallel edges are told apart by their position)"""
+    ids, j = [], 0
+    for r in rows:
+        while not np.array_equal(triples[j], r):
+            j += 1
+        ids.append(j)
+        j += 1
+    return ids
+
+
+# two components, a triangle, a self loop, a pair of parallel edges; and a small cyclic graph
+TINY = [(np.array([[0, 0, 1], [1, 0, 2], [2, 0, 0], [2, 0, 3], [3, 0, 3], [4, 0, 5], [4, 0, 5], [5, 0, 6]]), 8, (3, 6)),
+        (np.array([[0, 0, 1], [1, 0, 2], [2, 0, 3], [3, 0, 4], [0, 0, 2]]), 5, (2, 3))]
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_set_distribution_equals_the_reference_process(native, case):
+    """every possible outcome SET of a tiny graph: frequencies over 6,000 seeds on the device against 6,000 runs of the
+    reference's loop, each within 4.5 standard errors -- restarts into a second component, the double weight of an
+    edge whose two ends are both touched, self loops and parallel edges included"""
+    triples, V, ks = TINY[case]
+    triples = triples.astype(np.int32)
+    n = 6000
+    with native.Engine(V, 1, 4, 1, "block", 1, max_edges=len(triples)) as eng:
+        eng.neighborhood_reserve(triples)
+        for k in ks:
+            buf = native.DeviceBuffer(eng, 12 * k)
+            try:
+                dev = collections.Counter()
+                for seed in range(n):
+                    dev[outcome(draw(native, eng, buf, k, 1000 + seed))] += 1
+            finally:
+                buf.free()
+            ref = collections.Counter()
+            rng = np.random.RandomState(case * 10 + k)
+            for _ in range(n):
+                ref[outcome(triples[oracle.sample_edge_neighborhood(triples, V, k, rng)])] += 1
+            assert all(len(s) == k for s in dev)
+            for s in set(dev) | set(ref):
+                pa, pb = dev[s] / n, ref[s] / n
+                p = max((pa + pb) / 2, 1e-3)
+                se = np.sqrt(2 * p * (1 - min(p, 0.999)) / n)
+                assert abs(pa - pb) <= 4.5 * se, (case, k, s, pa, pb)
+
+
+def test_inclusion_frequencies_on_a_medium_graph(native):
+    """300 vertices, 1,500 edges with hubs and a few small components, 400 picks: per-edge inclusion frequency over 1,200
+    seeds against 1,200 runs of the reference's loop (5 standard errors, every edge), and the mean number of touched
+    vertices"""
+    rng = np.random.RandomState(3)
+    V, E, k, n = 300, 1500, 400, 1200
+    s = np.where(rng.rand(E) < 0.3, rng.randint(0, 6, E), rng.randint(0, 260, E))
+    o = rng.randint(0, 260, E)
+    triples = np.stack([s, rng.randint(0, 5, E), o], 1).astype(np.int32)
+    triples[-30:, 0] = rng.randint(260, 300, 30)            # small components hanging off vertices 260..299
+    triples[-30:, 2] = rng.randint(260, 300, 30)
+    with native.Engine(V, 5, 4, 1, "block", 1, max_edges=E) as eng:
+        eng.neighborhood_reserve(triples)
+        buf = native.DeviceBuffer(eng, 12 * k)
+        try:
+            inc_dev, verts_dev = np.zeros(E), 0.0
+            first = draw(native, eng, buf, k, 5)
+            assert np.array_equal(first, draw(native, eng, buf, k, 5))          # a function of the seed
+            assert not np.array_equal(first, draw(native, eng, buf, k, 6))
+            for seed in range(n):
+                ids = rows_to_ids(triples, draw(native, eng, buf, k, 77 + seed))
+                assert len(set(ids)) == k and ids == sorted(ids)                # exactly k distinct edges, edge order
+                inc_dev[ids] += 1
+                verts_dev += len(set(triples[ids][:, [0, 2]].ravel().tolist()))
+        finally:
+            buf.free()
+        with pytest.raises(native.RgcnError):
+            big = native.DeviceBuffer(eng, 12 * (E + 1))
+            try:
+                eng.sample_neighborhood_device(E + 1, 1, big)                   # more than the graph has
+            finally:
+                big.free()
+    inc_ref, verts_ref = np.zeros(E), 0.0
+    r2 = np.random.RandomState(4)
+    for _ in range(n):
+        ids = oracle.sample_edge_neighborhood(triples, V, k, r2)
+        inc_ref[ids] += 1
+        verts_ref += len(set(triples[ids][:, [0, 2]].ravel().tolist()))
+    pa, pb = inc_dev / n, inc_ref / n
+    p = np.clip((pa + pb) / 2, 1e-3, 0.999)
+    z = np.abs(pa - pb) / np.sqrt(2 * p * (1 - p) / n)
+    assert z.max() <= 5.0, (int(z.argmax()), float(z.max()), pa[z.argmax()], pb[z.argmax()])
+    assert abs(verts_dev - verts_ref) / n <= 2.0, (verts_dev / n, verts_ref / n)
+
+
+def test_training_graph_scale(native):
+    """the 272,115-edge synthetic FB15k-237 training graph, 30,000 picks (settings/gcn_block.exp's GraphBatchSize): the
+    batch is 30,000 distinct rows of the graph forming ONE connected patch (the giant component is never exhausted), and
+    the whole draw takes a few hundred microseconds of device time"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_graph", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    triples = bench.load_graph("synth:fb237_valid_test:272115")
+    V, k = 14541, 30000
+    with native.Engine(V, 237, 4, 1, "block", 1, max_edges=k) as eng:
+        eng.neighborhood_reserve(triples)
+        buf = native.DeviceBuffer(eng, 12 * k)
+        try:
+            rows = draw(native, eng, buf, k, 123)
+            eng.sync()
+            t0 = time.perf_counter()
+            for i in range(20):
+                eng.sample_neighborhood_device(k, 200 + i, buf)
+            eng.sync()
+            ms = (time.perf_counter() - t0) * 1e3 / 20
+            all_rows = native.DeviceBuffer(eng, 12 * len(triples))
+            try:
+                full = draw(native, eng, all_rows, len(triples), 9)             # the whole graph: every row once
+            finally:
+                all_rows.free()
+        finally:
+            buf.free()
+    print("device neighbourhood sampler: %.3f ms per 30,000-edge batch" % ms)
+    assert np.array_equal(full, triples)
+    key = lambda t: (t[:, 0].astype(np.int64) * 237 + t[:, 1]) * V + t[:, 2]    # noqa: E731  (triples are unique)
+    assert len(np.unique(key(rows))) == k and np.isin(key(rows), key(triples)).all()
+    # one connected patch: union-find over the drawn edges
+    parent = np.arange(V)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, _, b in rows:
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[ra] = rb
+    touched = np.unique(rows[:, [0, 2]])
+    assert len({find(v) for v in touched}) == 1
+    assert ms < 5.0
