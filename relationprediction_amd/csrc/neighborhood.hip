@@ -42,9 +42,9 @@ namespace rgcn {
 
 namespace {
 
-constexpr int kSweepLaunches = 48, kSegment = 256;
+constexpr int kSweepLaunches = 64, kSegment = 256;
 // sweeps per launch: the early launches move most vertices (stop test after 2), the tail trickles (4 per launch)
-constexpr int kEarlyLaunches = 12, kEarlySweeps = 2, kLateSweeps = 4;
+constexpr int kEarlyLaunches = 24, kEarlySweeps = 2, kLateSweeps = 4;
 // "something moved" flags: kFlagSlots per launch, each in its own 128-byte line -- sixteen thousand wavefronts storing
 // to ONE address serialise in the L2 (it was 30 of the 43 us of an early sweep)
 constexpr int kFlagSlots = 16, kFlagStride = 32;
@@ -67,15 +67,43 @@ __device__ __forceinline__ float end_clock(uint64_t seed, uint64_t end) {
   return -logf(((float)r + 0.5f) * (1.0f / 16777216.0f));
 }
 
+// What one draw is a function of: written by the host into a 64-byte block of device memory, read by every kernel --
+// the kernels' arguments never change, so the ~75 launches of a draw are ONE replayed hipGraph (launching them one by
+// one costs the host 0.3 ms a draw, more than the device spends).
+struct DrawParams {
+  uint64_t seed;
+  unsigned long long want;       // edges to take from the boundary component
+  int32_t* out;                  // [k,3] the batch
+  int32_t start, boundary;       // start vertex, boundary component
+  int32_t k, use_state;          // sample size; 1: components taken in full are marked in comp_state
+};
+
+// dist <- far (start vertex: 0), flags <- 0
+__global__ void __launch_bounds__(256) k_nbr_init(const DrawParams* __restrict__ p, uint32_t* __restrict__ dist, int V,
+                                                  int32_t* __restrict__ changed, int nflags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V) dist[i] = i == p->start ? 0u : kFar;
+  if (i < nflags) changed[i] = 0;
+}
+
 // d(v) <- min over v's incident edges of d(other) + X[other end].  One wavefront per SEGMENT of at most kSegment
 // adjacency entries of one vertex (a hub's ten thousand entries walked by one wavefront took 70 us a sweep), its minimum
-// merged with atomicMin on the non-negative float's bits -- a minimum does not depend on the order it is taken in;
-// several sweeps per launch (relaxations are monotone and idempotent: sweeps need no barrier between them, only the
-// stop test does).
-__global__ void __launch_bounds__(256) k_nbr_sweep(const int32_t* __restrict__ seg_v, const int32_t* __restrict__ seg_beg,
-                                                   const int32_t* __restrict__ seg_end, int nseg,
-                                                   const int32_t* __restrict__ adj_other, const int32_t* __restrict__ adj_end,
-                                                   uint64_t seed, uint32_t* dist, int32_t* changed, int it, int nsweeps) {
+// written with a plain store when the segment is the vertex's whole list (one writer), merged with atomicMin on the
+// non-negative float's bits when a hub's list has several (a minimum does not depend on the order it is taken in).
+// Device-scope atomics on a 58 KB array written from all eight XCDs cost ~1 us each (the line changes L2): an atomicMin
+// per moved vertex made the early sweeps, where most vertices move, 40 us each.  Plain stores are seen by the next
+// launch at the latest, which is all the stop test needs: a launch that moved nothing has read, at its first sweep,
+// values no one was writing -- the fixed point.
+// A lane keeps its (at most four) entries and their clocks in registers for the launch's sweeps; relaxations are
+// monotone and idempotent, so sweeps need no barrier between them, only the stop test does.  The first sweep of a
+// launch reads d with plain loads (whatever earlier launches wrote is visible), later ones with coherent loads (four
+// independent ones per lane: a coherent load that misses the local L2 costs microseconds while other XCDs write d).
+__global__ void __launch_bounds__(256) k_nbr_sweep(const DrawParams* __restrict__ p, const int32_t* __restrict__ seg_v,
+                                                   const int32_t* __restrict__ seg_beg, const int32_t* __restrict__ seg_end,
+                                                   int nseg, const int32_t* __restrict__ adj_other,
+                                                   const int32_t* __restrict__ adj_end, uint32_t* dist, int32_t* changed, int it,
+                                                   int nsweeps) {
+  static_assert(kSegment == 256, "four entries per lane");
   const int lane = threadIdx.x & 63;
   if (it > 0) {
     const int32_t f = lane < kFlagSlots ? changed[((it - 1) * kFlagSlots + lane) * kFlagStride] : 0;
@@ -83,19 +111,42 @@ __global__ void __launch_bounds__(256) k_nbr_sweep(const int32_t* __restrict__ s
   }
   const int g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (g >= nseg) return;
-  const int v = seg_v[g], beg = seg_beg[g], end = seg_end[g];
+  const int sv = seg_v[g], beg = seg_beg[g], end = seg_end[g];
+  const bool shared = sv < 0;                    // one of several segments of a hub's list (~v): merge with atomicMin
+  const int v = shared ? ~sv : sv;
+  const uint64_t seed = p->seed;
+  int other[4];
+  float clock[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = beg + lane + 64 * i;
+    other[i] = j < end ? adj_other[j] : -1;
+    clock[i] = j < end ? end_clock(seed, (uint64_t)(uint32_t)adj_end[j]) : 0.f;
+  }
+  uint32_t cur = dist[v];                        // a vertex with ONE segment has one writer: this wavefront
   bool moved = false;
   for (int sweep = 0; sweep < nsweeps; ++sweep) {
+    uint32_t du[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      du[i] = other[i] < 0 ? kFar : sweep == 0 ? dist[other[i]] : __atomic_load_n(&dist[other[i]], __ATOMIC_RELAXED);
     uint32_t best = kFar;
-    for (int j = beg + lane; j < end; j += 64) {
-      const uint32_t du = __atomic_load_n(&dist[adj_other[j]], __ATOMIC_RELAXED);
-      if (du != kFar) best = min(best, __float_as_uint(__uint_as_float(du) + end_clock(seed, (uint64_t)(uint32_t)adj_end[j])));
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (du[i] != kFar) best = min(best, __float_as_uint(__uint_as_float(du[i]) + clock[i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
-    if (lane == 0 && best < __atomic_load_n(&dist[v], __ATOMIC_RELAXED) && atomicMin(&dist[v], best) > best) moved = true;
+    if (best < cur) {
+      if (!shared) {
+        if (lane == 0) dist[v] = best;
+        moved = true;
+      } else if (lane == 0 && atomicMin(&dist[v], best) > best) {
+        moved = true;
+      }
+      cur = best;
+    }
   }
-  if (moved) {
+  if (lane == 0 && moved) {
     int32_t* flag = changed + (it * kFlagSlots + (g & (kFlagSlots - 1))) * kFlagStride;
     if (__atomic_load_n(flag, __ATOMIC_RELAXED) == 0) __atomic_store_n(flag, 1, __ATOMIC_RELAXED);
   }
@@ -108,13 +159,15 @@ __global__ void k_nbr_check(const int32_t* __restrict__ changed, int last, int32
 }
 
 // per edge of the boundary component: (pick time | edge id); every other edge: the largest key
-__global__ void k_nbr_keys(const int32_t* __restrict__ tri, int n, uint64_t seed, const int32_t* __restrict__ comp,
-                           int boundary, const uint32_t* __restrict__ dist, unsigned long long* __restrict__ tkey) {
+__global__ void k_nbr_keys(const DrawParams* __restrict__ p, const int32_t* __restrict__ tri, int n,
+                           const int32_t* __restrict__ comp, const uint32_t* __restrict__ dist,
+                           unsigned long long* __restrict__ tkey) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const int s = tri[3 * e], o = tri[3 * e + 2];
+  const uint64_t seed = p->seed;
   unsigned long long key = ~0ull;
-  if (comp[s] == boundary) {
+  if (comp[s] == p->boundary) {
     const float ts = __uint_as_float(dist[s]) + end_clock(seed, 2ull * (uint64_t)e);
     const float to = __uint_as_float(dist[o]) + end_clock(seed, 2ull * (uint64_t)e + 1ull);
     key = ((unsigned long long)__float_as_uint(fminf(ts, to)) << 32) | (unsigned long long)(uint32_t)e;
@@ -127,9 +180,9 @@ struct SelState {
   unsigned long long prefix, want;
 };
 __device__ __forceinline__ int digit_shift(int pass) { return pass < 5 ? 52 - kDigitBits * pass : 0; }
-__global__ void k_nbr_set_want(SelState* __restrict__ s, unsigned long long want) {
+__global__ void k_nbr_set_want(const DrawParams* __restrict__ p, SelState* __restrict__ s) {
   s->prefix = 0ull;
-  s->want = want;
+  s->want = p->want;
 }
 __global__ void __launch_bounds__(1024) k_nbr_hist(int pass, const unsigned long long* __restrict__ tkey, int n,
                                                    const SelState* __restrict__ state, uint32_t* __restrict__ hist) {
@@ -186,12 +239,12 @@ __global__ void __launch_bounds__(1024) k_nbr_scan(int pass, uint32_t* __restric
 // in the batch: the boundary component's edges up to the threshold key, and every edge of a component taken in full
 __device__ __forceinline__ bool nbr_included(int e, const int32_t* __restrict__ tri, const unsigned long long* __restrict__ tkey,
                                              unsigned long long thresh, const int32_t* __restrict__ comp,
-                                             const uint8_t* __restrict__ comp_state) {
+                                             const uint8_t* __restrict__ comp_state, bool use_state) {
   if (tkey[e] <= thresh) return true;
-  return comp_state != nullptr && comp_state[comp[tri[3 * e]]] != 0;
+  return use_state && comp_state[comp[tri[3 * e]]] != 0;
 }
 constexpr int kCompactBlock = 1024;
-__global__ void __launch_bounds__(kCompactBlock) k_nbr_count(const int32_t* __restrict__ tri,
+__global__ void __launch_bounds__(kCompactBlock) k_nbr_count(const DrawParams* __restrict__ p, const int32_t* __restrict__ tri,
                                                             const unsigned long long* __restrict__ tkey, int n,
                                                             const SelState* __restrict__ state,
                                                             const int32_t* __restrict__ comp,
@@ -199,7 +252,7 @@ __global__ void __launch_bounds__(kCompactBlock) k_nbr_count(const int32_t* __re
                                                             uint32_t* __restrict__ bcnt) {
   __shared__ uint32_t wcnt[kCompactBlock / 64];
   const int e = blockIdx.x * kCompactBlock + threadIdx.x;
-  const bool inc = e < n && nbr_included(e, tri, tkey, state->prefix, comp, comp_state);
+  const bool inc = e < n && nbr_included(e, tri, tkey, state->prefix, comp, comp_state, p->use_state != 0);
   const unsigned long long vote = __ballot(inc);
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(vote);
   __syncthreads();
@@ -210,7 +263,7 @@ __global__ void __launch_bounds__(kCompactBlock) k_nbr_count(const int32_t* __re
   }
 }
 // exclusive scan of the block counts (one workgroup, any number of blocks); the total must be the sample size
-__global__ void __launch_bounds__(1024) k_nbr_offsets(uint32_t* __restrict__ bcnt, int nblocks, int want_total,
+__global__ void __launch_bounds__(1024) k_nbr_offsets(const DrawParams* __restrict__ p, uint32_t* __restrict__ bcnt, int nblocks,
                                                       int32_t* errflag) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
@@ -239,19 +292,18 @@ __global__ void __launch_bounds__(1024) k_nbr_offsets(uint32_t* __restrict__ bcn
     if (tid == 0) carry_s = carry + total;
     __syncthreads();
   }
-  if (tid == 0 && (int)carry_s != want_total) atomicOr(errflag, 8);
+  if (tid == 0 && (int)carry_s != p->k) atomicOr(errflag, 8);
 }
 // the chosen edges' rows, in edge order, to the caller's batch buffer
-__global__ void __launch_bounds__(kCompactBlock) k_nbr_write(const int32_t* __restrict__ tri,
+__global__ void __launch_bounds__(kCompactBlock) k_nbr_write(const DrawParams* __restrict__ p, const int32_t* __restrict__ tri,
                                                             const unsigned long long* __restrict__ tkey, int n,
                                                             const SelState* __restrict__ state,
                                                             const int32_t* __restrict__ comp,
                                                             const uint8_t* __restrict__ comp_state,
-                                                            const uint32_t* __restrict__ boff, int cap,
-                                                            int32_t* __restrict__ out) {
+                                                            const uint32_t* __restrict__ boff) {
   __shared__ uint32_t wcnt[kCompactBlock / 64];
   const int e = blockIdx.x * kCompactBlock + threadIdx.x;
-  const bool inc = e < n && nbr_included(e, tri, tkey, state->prefix, comp, comp_state);
+  const bool inc = e < n && nbr_included(e, tri, tkey, state->prefix, comp, comp_state, p->use_state != 0);
   const unsigned long long vote = __ballot(inc);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) wcnt[wid] = (uint32_t)__popcll(vote);
@@ -259,7 +311,8 @@ __global__ void __launch_bounds__(kCompactBlock) k_nbr_write(const int32_t* __re
   if (!inc) return;
   uint32_t slot = boff[blockIdx.x] + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
   for (int w = 0; w < wid; ++w) slot += wcnt[w];
-  if ((int)slot >= cap) return;
+  if ((int)slot >= p->k) return;
+  int32_t* __restrict__ out = p->out;
   out[3 * slot] = tri[3 * e];
   out[3 * slot + 1] = tri[3 * e + 1];
   out[3 * slot + 2] = tri[3 * e + 2];
@@ -284,9 +337,12 @@ int find_root(std::vector<int32_t>& parent, int x) {
 void neighborhood_free(rgcn_ctx* c) {
   NeighborhoodBufs& q = c->nbr;
   void* ptrs[] = {q.triples, q.seg_v, q.seg_beg, q.seg_end, q.adj_other, q.adj_end, q.comp, q.comp_state, q.dist, q.tkey, q.hist, q.state,
-                  q.changed, q.bcnt};
+                  q.changed, q.bcnt, q.params};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (q.draw_exec) (void)hipGraphExecDestroy(q.draw_exec);
+  if (q.draw_graph) (void)hipGraphDestroy(q.draw_graph);
+  if (q.capture_stream) (void)hipStreamDestroy(q.capture_stream);
   q = NeighborhoodBufs();
 }
 
@@ -319,7 +375,7 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   std::vector<int32_t> seg_v, seg_beg, seg_end;
   for (int v = 0; v < V; ++v)
     for (int b0 = ptr[v]; b0 < ptr[v + 1]; b0 += kSegment) {
-      seg_v.push_back(v);
+      seg_v.push_back(ptr[v + 1] - ptr[v] > kSegment ? ~v : v);
       seg_beg.push_back(b0);
       seg_end.push_back(std::min(ptr[v + 1], b0 + kSegment));
     }
@@ -351,6 +407,7 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   RGCN_TRY(dalloc(c, &q.state, (size_t)2));
   RGCN_TRY(dalloc(c, &q.changed, (size_t)kSweepLaunches * kFlagSlots * kFlagStride));
   RGCN_TRY(dalloc(c, &q.bcnt, nb));
+  RGCN_HIP(c, hipMalloc(&q.params, sizeof(DrawParams)));
   hipStream_t st = c->stream;
   RGCN_HIP(c, hipMemcpyAsync(q.triples, tri, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
   if (!other.empty()) {
@@ -367,11 +424,54 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   return RGCN_OK;
 }
 
+// the kernels of one draw, recorded into a hipGraph on a stream of its own (every per-draw quantity is read from q.params)
+static rgcn_status record_draw(rgcn_ctx* c) {
+  NeighborhoodBufs& q = c->nbr;
+  const int n = (int)q.n, V = c->V, T = 256;
+  static const int launches = [] {              // RGCN_NBR_LAUNCHES: a smaller budget, for measuring how many a graph needs
+    const char* e = getenv("RGCN_NBR_LAUNCHES");
+    return e ? std::min(std::max(atoi(e), 1), kSweepLaunches) : kSweepLaunches;
+  }();
+  if (!q.capture_stream) RGCN_HIP(c, hipStreamCreateWithFlags(&q.capture_stream, hipStreamNonBlocking));
+  hipStream_t st = q.capture_stream;
+  const DrawParams* p = reinterpret_cast<const DrawParams*>(q.params);
+  const int nflags = kSweepLaunches * kFlagSlots * kFlagStride;
+  const dim3 ge((unsigned)((n + T - 1) / T)), gw((unsigned)(((size_t)std::max(q.nseg, 1) * 64 + T - 1) / T)), bt(T);
+  const dim3 gi((unsigned)((std::max(V, nflags) + T - 1) / T));
+  RGCN_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  hipLaunchKernelGGL(k_nbr_init, gi, bt, 0, st, p, q.dist, V, q.changed, nflags);
+  for (int it = 0; it < launches; ++it)
+    hipLaunchKernelGGL(k_nbr_sweep, gw, bt, 0, st, p, q.seg_v, q.seg_beg, q.seg_end, q.nseg, q.adj_other, q.adj_end, q.dist,
+                       q.changed, it, it < kEarlyLaunches ? kEarlySweeps : kLateSweeps);
+  hipLaunchKernelGGL(k_nbr_check, dim3(1), dim3(64), 0, st, q.changed, launches - 1, c->g.errflag);
+  hipLaunchKernelGGL(k_nbr_keys, ge, bt, 0, st, p, q.triples, n, q.comp, q.dist, q.tkey);
+  SelState* state = reinterpret_cast<SelState*>(q.state);
+  hipLaunchKernelGGL(k_nbr_set_want, dim3(1), dim3(1), 0, st, p, state);
+  const int nblocks = (n + kCompactBlock - 1) / kCompactBlock;
+  for (int pass = 0; pass < kPasses; ++pass) {
+    hipLaunchKernelGGL(k_nbr_hist, dim3(nblocks), dim3(1024), 0, st, pass, q.tkey, n, state, q.hist);
+    hipLaunchKernelGGL(k_nbr_scan, dim3(1), dim3(1024), 0, st, pass, q.hist, state);
+  }
+  hipLaunchKernelGGL(k_nbr_count, dim3(nblocks), dim3(kCompactBlock), 0, st, p, q.triples, q.tkey, n, state, q.comp,
+                     q.comp_state, q.bcnt);
+  hipLaunchKernelGGL(k_nbr_offsets, dim3(1), dim3(1024), 0, st, p, q.bcnt, nblocks, c->g.errflag);
+  hipLaunchKernelGGL(k_nbr_write, dim3(nblocks), dim3(kCompactBlock), 0, st, p, q.triples, q.tkey, n, state, q.comp,
+                     q.comp_state, q.bcnt);
+  const hipError_t e1 = hipGetLastError();
+  const hipError_t e2 = hipStreamEndCapture(st, &q.draw_graph);
+  if (e1 != hipSuccess || e2 != hipSuccess || !q.draw_graph)
+    RGCN_FAIL(c, RGCN_ERR_HIP, std::string("device neighbourhood sampler: recording the draw failed: ") +
+                                   hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  RGCN_HIP(c, hipGraphInstantiate(&q.draw_exec, q.draw_graph, nullptr, nullptr, 0));
+  return RGCN_OK;
+}
+
 // sample_size rows of the training graph -> batch_out [sample_size, 3], in edge order; runs on the current stream
 rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t k64, uint64_t seed, int32_t* batch_out, bool on_prefetch_stream) {
   NeighborhoodBufs& q = c->nbr;
-  const int n = (int)q.n, k = (int)k64, V = c->V, T = 256;
+  const int n = (int)q.n, k = (int)k64, V = c->V;
   if (k == 0) return RGCN_OK;
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "the device neighbourhood sampler uploads the draw's parameters: not while a hipGraph is being captured");
   // ---- host: the vertex priorities settle which components are taken in full, where the budget runs out, and the
   // start vertex there
   std::vector<uint64_t> cmin((size_t)q.ncomp, ~0ull);
@@ -405,31 +505,19 @@ rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t k64, uint64_t seed, int32_t
   hipStream_t st = c->stream;
   if (any_full)
     RGCN_TRY(rgcn_copy_to_device_async(c, q.comp_state, q.comp_state_h.data(), (int64_t)q.ncomp, on_prefetch_stream ? 1 : 0));
-  const uint8_t* comp_state = any_full ? q.comp_state : nullptr;
-  // ---- device
-  const dim3 ge((unsigned)((n + T - 1) / T)), gw((unsigned)(((size_t)std::max(q.nseg, 1) * 64 + T - 1) / T)), bt(T);
+  DrawParams dp;
+  dp.seed = seed;
+  dp.want = (unsigned long long)want;
+  dp.out = batch_out;
+  dp.start = cstart[boundary];
+  dp.boundary = boundary;
+  dp.k = k;
+  dp.use_state = any_full ? 1 : 0;
+  RGCN_TRY(rgcn_copy_to_device_async(c, q.params, &dp, (int64_t)sizeof(dp), on_prefetch_stream ? 1 : 0));
+  // ---- device: one graph, recorded at the first draw
+  if (!q.draw_exec) RGCN_TRY(record_draw(c));
   ProfScope ps(c, "nbr_sample", 8.0 * 2.0 * n * 12 + 32.0 * n, 0, 12.0 * n + 12.0 * k);
-  RGCN_HIP(c, hipMemsetAsync(q.dist, 0x7f, sizeof(uint32_t) * (size_t)V, st));
-  RGCN_HIP(c, hipMemsetAsync(q.dist + cstart[boundary], 0, sizeof(uint32_t), st));      // the start: touched at time 0
-  RGCN_HIP(c, hipMemsetAsync(q.changed, 0, sizeof(int32_t) * kSweepLaunches * kFlagSlots * kFlagStride, st));
-  for (int it = 0; it < kSweepLaunches; ++it)
-    hipLaunchKernelGGL(k_nbr_sweep, gw, bt, 0, st, q.seg_v, q.seg_beg, q.seg_end, q.nseg, q.adj_other, q.adj_end, seed, q.dist,
-                       q.changed, it, it < kEarlyLaunches ? kEarlySweeps : kLateSweeps);
-  hipLaunchKernelGGL(k_nbr_check, dim3(1), dim3(64), 0, st, q.changed, kSweepLaunches - 1, c->g.errflag);
-  hipLaunchKernelGGL(k_nbr_keys, ge, bt, 0, st, q.triples, n, seed, q.comp, boundary, q.dist, q.tkey);
-  SelState* state = reinterpret_cast<SelState*>(q.state);
-  hipLaunchKernelGGL(k_nbr_set_want, dim3(1), dim3(1), 0, st, state, (unsigned long long)want);
-  const int nblocks = (n + kCompactBlock - 1) / kCompactBlock;
-  for (int pass = 0; pass < kPasses; ++pass) {
-    hipLaunchKernelGGL(k_nbr_hist, dim3(nblocks), dim3(1024), 0, st, pass, q.tkey, n, state, q.hist);
-    hipLaunchKernelGGL(k_nbr_scan, dim3(1), dim3(1024), 0, st, pass, q.hist, state);
-  }
-  hipLaunchKernelGGL(k_nbr_count, dim3(nblocks), dim3(kCompactBlock), 0, st, q.triples, q.tkey, n, state, q.comp, comp_state,
-                     q.bcnt);
-  hipLaunchKernelGGL(k_nbr_offsets, dim3(1), dim3(1024), 0, st, q.bcnt, nblocks, k, c->g.errflag);
-  hipLaunchKernelGGL(k_nbr_write, dim3(nblocks), dim3(kCompactBlock), 0, st, q.triples, q.tkey, n, state, q.comp, comp_state,
-                     q.bcnt, k, batch_out);
-  RGCN_HIP(c, hipGetLastError());
+  RGCN_HIP(c, hipGraphLaunch(q.draw_exec, st));
   return RGCN_OK;
 }
 

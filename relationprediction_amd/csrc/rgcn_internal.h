@@ -236,6 +236,10 @@ struct NeighborhoodBufs {
   unsigned long long* state = nullptr;   // select state (prefix, wanted rank)
   int32_t* changed = nullptr;            // per-launch "something moved" flags of the relaxation
   uint32_t* bcnt = nullptr;              // per-block counts / offsets of the compaction
+  void* params = nullptr;                // the draw's parameters (seed, start vertex, ...: neighborhood.hip DrawParams)
+  hipGraph_t draw_graph = nullptr;       // the kernels of one draw, recorded once, replayed per draw
+  hipGraphExec_t draw_exec = nullptr;
+  hipStream_t capture_stream = nullptr;
   // host side (components are a property of the graph: found once, at reserve)
   std::vector<int32_t> comp_h;           // [V]
   std::vector<int64_t> comp_edges_h;     // [ncomp] edges per component

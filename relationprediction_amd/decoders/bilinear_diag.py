@@ -95,6 +95,9 @@ class BilinearDiag(Model):
     def device_stage_minibatch(self, minibatch):
         self.next_component.get_runtime().stage_minibatch(minibatch)
 
+    def device_presample_minibatch(self, minibatch):
+        self.next_component.get_runtime().presample_minibatch(minibatch)
+
     def device_loss(self):
         return self.next_component.get_runtime().loss()
 

@@ -201,6 +201,9 @@ class Model(object):
     def device_stage_minibatch(self, *args):
         return self.__delegate__('device_stage_minibatch', *args)
 
+    def device_presample_minibatch(self, *args):
+        return self.__delegate__('device_presample_minibatch', *args)
+
     def device_loss(self):
         return self.__delegate__('device_loss')
 

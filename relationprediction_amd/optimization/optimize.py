@@ -324,6 +324,14 @@ class HipOptimizer(object):
         else:
             stage(processed_batch[0], None)
 
+    def presample(self, processed_batch):
+        """A device-sampled minibatch is a function of its seed alone: draw it a whole iteration before its graph is
+        prepared (runtime.presample_minibatch), so that the sampler's chain of short kernels has the length of a step
+        to finish in beside the step, instead of standing between the step and the next one."""
+        pre = getattr(self.model, 'device_presample_minibatch', None)
+        if pre is not None and isinstance(processed_batch, DeviceMinibatch) and processed_batch.sample is not None:
+            pre(processed_batch)
+
     def _sample_transformer(self):
         """The SampleTransformer if it sits directly on the data source (the only place the reference puts it
         when no Minibatches component is configured)."""
@@ -378,14 +386,20 @@ class HipOptimizer(object):
         i = 0
         batches = self._batches()
         processed = next(batches, None)
+        ahead = None                                         # a device-sampled batch fetched one iteration early
         while processed is not None:
             i += 1
             self.stack.set_iteration(i)
             self.update_from_batch(processed, seed=int(np.random.randint(0, 2 ** 31 - 1)))
             # host work of the next iteration (or the wait for a background-built batch) while the device runs
-            processed = next(batches, None)
+            processed = ahead if ahead is not None else next(batches, None)
+            ahead = None
             if processed is not None:
                 self.stage(processed)                        # upload + graph prep of the next step, beside this one
+                if isinstance(processed, DeviceMinibatch) and processed.sample is not None:
+                    ahead = next(batches, None)              # ... and the draw of the batch after it, behind that
+                    if ahead is not None:
+                        self.presample(ahead)
             train_loss = self.model.device_loss()            # synchronises with the step
             if self.stack.postprocess(train_loss) == 'stop':
                 print("Stopping training.")

@@ -128,14 +128,32 @@ class EncoderRuntime(object):
         self._staged = (graph_edges, batch, slot, gd, len(g), bd, nb)
 
     def _sampled_batch(self, mb, slot_name, on_prefetch_stream):
-        """the graph batch of a device-sampled minibatch: drawn into a device buffer by the device sampler"""
+        """the graph batch of a device-sampled minibatch: drawn into a device buffer by the device sampler (or
+        already drawn there by presample_minibatch)"""
         train, size, seed = mb.sample
+        pre = getattr(self, "_presampled", None)
+        if pre is not None and pre[0] is mb:
+            self._presampled = None
+            return pre[1], int(size)
         if getattr(self, "_nbr_graph", None) is not train:
             self.engine.neighborhood_reserve(train)        # the training graph moves to the device once
             self._nbr_graph = train
         bd = self._buffer(slot_name, 12 * int(size))
         self.engine.sample_neighborhood_device(int(size), int(seed), bd, on_prefetch_stream=on_prefetch_stream)
         return bd, int(size)
+
+    def presample_minibatch(self, mb):
+        """Draw the graph batch of the minibatch AFTER the staged one, on the prefetch stream behind the staged one's
+        graph preparation.  Three buffers in turn: the step that runs reads one, the staged preparation read the
+        second, this draw writes the third -- and it is ordered, on the prefetch stream, behind a preparation that
+        waited for the step which last read that third buffer."""
+        if getattr(mb, "sample", None) is None or int(mb.sample[1]) > self.engine.max_edges:
+            return
+        ring = getattr(self, "_sample_ring", 0)
+        self._sample_ring = (ring + 1) % 3
+        self._presampled = None
+        bd, _ = self._sampled_batch(mb, "sampled%d" % ring, True)
+        self._presampled = (mb, bd)
 
     def stage_minibatch(self, mb):
         """The device-dropout flavour of stage(): ONE upload (the graph batch; it is the edge-dropout input and the

@@ -118,3 +118,28 @@ def test_train_driver_end_to_end(tmp_path, capsys, concat, nb, extra):
     raw, filt = model.device_ranks(train_triples, queries, True, ptr, queries[:, 2].astype(np.int32))
     host_raw = np.array([(row >= row[o]).sum() for row, o in zip(all_obj, queries[:, 2])])
     assert np.abs(raw - host_raw).max() <= 1 and (filt == raw).all() # filter = gold only -> filtered == raw
+
+
+def test_lookahead_draw_leaves_the_trajectory_unchanged(tmp_path, capsys, monkeypatch):
+    """A device-sampled batch is a function of its seed: drawing it one iteration early (HipOptimizer.presample, three
+    batch buffers in turn) trains to the same weights, bit for bit, as drawing it when its graph is prepared."""
+    from relationprediction_amd import train
+    from relationprediction_amd.optimization import optimize
+    data = str(tmp_path / "data")
+    write_dataset(data)
+    weights = []
+    for k, lookahead in enumerate((True, False)):
+        os.makedirs(str(tmp_path / ("models%d" % k)))
+        exp = str(tmp_path / ("models%d" % k) / "Toy")
+        settings = tmp_path / ("toy%d.exp" % k)
+        settings.write_text(SETTINGS % dict(nb=4, concat="Yes", exp=exp))
+        if not lookahead:
+            monkeypatch.setattr(optimize.HipOptimizer, "presample", lambda self, batch: None)
+        np.random.seed(0)
+        model, iterations = train.main(["--settings", str(settings), "--dataset", data, "--max-iterations", "25"])
+        assert iterations == 25
+        weights.append({v.name: np.array(v.value()) for v in model.get_weights()})
+    capsys.readouterr()
+    assert weights[0].keys() == weights[1].keys()
+    for name in weights[0]:
+        assert np.array_equal(weights[0][name], weights[1][name]), name
