@@ -15,6 +15,8 @@
 //   K3  relation gradient = per-relation chunks of 128 triples -> slab, ordered reduce per relation.
 // The two CSRs depend only on X, not on the encoder: they are built on a side stream while the encoder's
 // forward pass runs (rgcn_train_step_device).
+#include <algorithm>
+
 #include "rgcn_internal.h"
 
 namespace rgcn {
@@ -52,8 +54,8 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_
 }
 
 // ---- CSR construction -----------------------------------------------------------------------
-__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t* keyv,
-                           uint32_t* keyr, int32_t* errflag) {
+__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t rel_mul, uint32_t period,
+                           uint32_t* keyv, uint32_t* keyr, int32_t* errflag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * N) return;
   const bool subj = i < N;
@@ -62,13 +64,14 @@ __global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, u
   const bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
   if (subj && !ok) atomicOr(errflag, 2);
   keyv[i] = ok ? (uint32_t)(subj ? s : o) : (uint32_t)V;
-  if (subj) keyr[n] = ok ? (uint32_t)r : (uint32_t)R;
+  // rel_mul > 1: a tiled batch (DecoderBufs::tiled_period) -- within a relation, the copies of one triple side by side
+  if (subj) keyr[n] = ok ? (uint32_t)r * rel_mul + ((uint32_t)n % period) % rel_mul : (uint32_t)R * rel_mul;
 }
 
 // block 0: relation offsets + exclusive scan of the chunk counts; blocks 1..: entity row offsets + long rows
 __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ keyv_s,
                                                    const uint32_t* __restrict__ keyr_s, int N, int V, int R,
-                                                   int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
+                                                   uint32_t rel_mul, int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
                                                    int32_t* long_first, int32_t* long_cnt, int32_t* piece_row,
                                                    int32_t* piece_k, int piece_cap, int32_t* rel_ptr,
                                                    int32_t* chunk_ptr) {
@@ -82,9 +85,9 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
       const int r = base + tid;
       int lo = 0, nchunks = 0;
       if (r <= R) {
-        lo = lower_bound_u32(keyr_s, N, (uint32_t)r);
+        lo = lower_bound_u32(keyr_s, N, (uint32_t)r * rel_mul);
         rel_ptr[r] = lo;
-        if (r < R) nchunks = (lower_bound_u32(keyr_s, N, (uint32_t)(r + 1)) - lo + kDecChunk - 1) / kDecChunk;
+        if (r < R) nchunks = (lower_bound_u32(keyr_s, N, (uint32_t)(r + 1) * rel_mul) - lo + kDecChunk - 1) / kDecChunk;
       }
       int incl = nchunks;
 #pragma unroll
@@ -507,49 +510,85 @@ __global__ void __launch_bounds__(256) k_dec_energy_rel(const float* __restrict_
     if (c < nvec) vload<VEC>(Wr + (size_t)rel * d + (size_t)c * VEC, rr[t]);
   }
   float xent = 0.f, sq = 0.f;                        // accumulated by lane 0 of each wave
-  for (int j = beg + wave; j < end; j += 4) {
-    const int n = permr[j];
-    const int s = X[3 * n], o = X[3 * n + 2];        // in range: invalid triples sort behind rel_ptr[R]
-    const float* p1 = codes + (size_t)s * d;
-    const float* p2 = codes + (size_t)o * d;
-    float a[T][VEC], e[T][VEC];
-    float x = 0.f, q = 0.f;
+  // Two triples per turn (this wave's j and j + 4: the order it always took them in), their four entity rows in
+  // flight together, and the NEXT turn's indices fetched before this turn's rows are waited for: the kernel is bound
+  // by the dependent chain permr -> X -> rows -> shuffle reduction of one triple after another, not by bytes (the
+  // tiled order below halves its HBM traffic and took 10 % off its time).
+  int j = beg + wave;
+  int n0 = j < end ? permr[j] : -1, n1 = j + 4 < end ? permr[j + 4] : -1;
+  int s0 = 0, o0 = 0, s1 = 0, o1 = 0;
+  if (n0 >= 0) { s0 = X[3 * n0]; o0 = X[3 * n0 + 2]; }          // in range: invalid triples sort behind rel_ptr[R]
+  if (n1 >= 0) { s1 = X[3 * n1]; o1 = X[3 * n1 + 2]; }
+  while (n0 >= 0) {
+    const bool two = n1 >= 0;
+    float a[2][T][VEC], e[2][T][VEC];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int c = lane + 64 * t;
+    for (int u = 0; u < 2; ++u) {
+      const float* p1 = codes + (size_t)(u ? s1 : s0) * d;
+      const float* p2 = codes + (size_t)(u ? o1 : o0) * d;
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) { a[t][k] = 0.f; e[t][k] = 0.f; }
-      if (c < nvec) {
-        vload<VEC>(p1 + (size_t)c * VEC, a[t]);
-        vload<VEC>(p2 + (size_t)c * VEC, e[t]);
+      for (int t = 0; t < T; ++t) {
+        const int c = lane + 64 * t;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          x = fmaf(a[t][k] * rr[t][k], e[t][k], x);
-          q += a[t][k] * a[t][k] + rr[t][k] * rr[t][k] + e[t][k] * e[t][k];
+        for (int k = 0; k < VEC; ++k) { a[u][t][k] = 0.f; e[u][t][k] = 0.f; }
+        if (c < nvec && (u == 0 || two)) {
+          vload<VEC>(p1 + (size_t)c * VEC, a[u][t]);
+          vload<VEC>(p2 + (size_t)c * VEC, e[u][t]);
         }
       }
     }
+    const int m0 = n0, m1 = n1;
+    const float y0 = Y[m0], y1 = two ? Y[m1] : 0.f;
+    j += 8;
+    n0 = j < end ? permr[j] : -1;
+    n1 = j + 4 < end ? permr[j + 4] : -1;
+    if (n0 >= 0) { s0 = X[3 * n0]; o0 = X[3 * n0 + 2]; }
+    if (n1 >= 0) { s1 = X[3 * n1]; o1 = X[3 * n1 + 2]; }
+    float x[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int c = lane + 64 * t;
+        if (c < nvec) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            x[u] = fmaf(a[u][t][k] * rr[t][k], e[u][t][k], x[u]);
+            q[u] += a[u][t][k] * a[u][t][k] + rr[t][k] * rr[t][k] + e[u][t][k] * e[u][t][k];
+          }
+        }
+      }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      x += __shfl_down(x, off, 64);
-      q += __shfl_down(q, off, 64);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        x[u] += __shfl_down(x[u], off, 64);
+        q[u] += __shfl_down(q[u], off, 64);
+      }
     }
-    float g = 0.f;
+    float g[2] = {0.f, 0.f};
     if (lane == 0) {
-      const float y = Y[n];
-      const float ax = fabsf(x);
-      const float ex = __expf(-ax);
-      const float sig = x >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
-      g = (sig - y) / (float)N;
-      dx[n] = g;
-      xent += (1.0f - y) * x + log1pf(ex) + fmaxf(-x, 0.f);
-      sq += q;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        const float y = u ? y1 : y0;
+        const float ax = fabsf(x[u]);
+        const float ex = __expf(-ax);
+        const float sig = x[u] >= 0.f ? 1.0f / (1.0f + ex) : ex / (1.0f + ex);
+        g[u] = (sig - y) / (float)N;
+        dx[u ? m1 : m0] = g[u];
+        xent += (1.0f - y) * x[u] + log1pf(ex) + fmaxf(-x[u], 0.f);
+        sq += q[u];
+      }
     }
-    g = __shfl(g, 0, 64);
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int u = 0; u < 2; ++u) {
+      const float gu = __shfl(g[u], 0, 64);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[t][k] = fmaf(g * a[t][k], e[t][k], acc[t][k]);
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[t][k] = fmaf(gu * a[u][t][k], e[u][t][k], acc[t][k]);
+    }
   }
   float* red = sm;
   float* lossred = sm + (size_t)4 * d;
@@ -612,6 +651,9 @@ rgcn_status negative_sample(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, in
   hipLaunchKernelGGL(k_negative_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, batch_dev,
                      (int)n, rate, c->V, seed, c->capturing ? c->replay_counter : nullptr, X, Y);
   RGCN_HIP(c, hipGetLastError());
+  c->dec.tiled_X = X;
+  c->dec.tiled_period = n;
+  c->dec.tiled_N = total;
   return RGCN_OK;
 }
 
@@ -669,24 +711,34 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t 
   q.N = N;
   q.N_total = N_total > 0 ? N_total : N64;
   q.X = X;
+  // a batch the negative sampler tiled: relation sort by (relation, row mod period), if the key fits 32 bits
+  static const bool tiled_order = !(getenv("RGCN_DEC_TILED") && atoi(getenv("RGCN_DEC_TILED")) == 0);
+  // (sort keys are below 2^24, csr_sort.hip: when (R + 1) * period is not, triples fall into as many buckets per
+  // relation as fit -- two triples of one relation rarely share one)
+  q.rel_mul = 1;
+  uint32_t period = 1;
+  if (tiled_order && X == q.tiled_X && N64 == q.tiled_N && (N_total <= 0 || N_total == N64) && q.tiled_period > 1 && q.tiled_period < (1 << 30)) {
+    period = (uint32_t)q.tiled_period;
+    q.rel_mul = std::max<uint32_t>(1u, std::min<uint32_t>(period, ((1u << 24) - 1u) / (uint32_t)(R + 1)));
+  }
   RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, 2 * sizeof(int32_t), c->stream));
   const int T = 256;
   if (N > 0) {
     {
       ProfScope ps(c, "dec_keys", 36.0 * N, 0);
-      hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, q.keyv,
+      hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, q.rel_mul, period, q.keyv,
                          q.keyr, c->g.errflag);
     }
     // entity incidences (2N, by entity) and triples (N, by relation): one call, shared launches
     SortSpec sp[2];
     sp[0] = SortSpec{q.keyv, q.keyv_s, q.permv, q.keyv_t, q.valv, nullptr, q.tablev, (int64_t)2 * N, (uint32_t)V};
-    sp[1] = SortSpec{q.keyr, q.keyr_s, q.permr, q.keyr_t, q.valr, nullptr, q.tabler, (int64_t)N, (uint32_t)R};
+    sp[1] = SortSpec{q.keyr, q.keyr_s, q.permr, q.keyr_t, q.valr, nullptr, q.tabler, (int64_t)N, (uint32_t)R * q.rel_mul};
     RGCN_TRY(sort_pairs(c, "dec_sort", 2, sp));
   }
   {
     ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);
     hipLaunchKernelGGL(k_dec_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, q.keyv_s, q.keyr_s, N,
-                       V, R, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
+                       V, R, q.rel_mul, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
                        q.piece_k, q.piece_cap, q.rel_ptr, q.chunk_ptr);
   }
   if (N > 0) {
