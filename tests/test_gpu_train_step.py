@@ -67,6 +67,46 @@ def test_device_decoder_matches_oracle(native, V, R, d, nb, E, hub):
         assert_close(grads[k], og[k], rel=5e-4, name=k)
 
 
+@pytest.mark.parametrize("V,R,n,rate", [(300, 7, 900, 10), (1400, 1345, 13000, 1)])
+def test_decoder_on_a_tiled_batch(native, V, R, n, rate):
+    """A batch the device negative sampler tiled (NegativeSampler.transform's layout) is sorted by (relation, row mod
+    batch size), so that the copies of a triple share their row fetches in a relation chunk -- another ORDER of the same
+    sums: loss and gradients against the oracle, and against the untiled order (the same rows in a buffer the sampler
+    did not write); R = 1,345 with n = 13,000 exceeds the 24-bit sort key, where triples fall into buckets per relation."""
+    d, L, nb, E = 20, 1, 4, 200
+    params, triples, masks, _ = make_case(V, R, d, L, "block", nb, E, seed=3)
+    rng = np.random.RandomState(8)
+    batch = np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1).astype(np.int32)
+    N = n * (rate + 1)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, masks=masks)
+        codes = eng.codes()
+        eng.decoder_reserve(N)
+        bd, xd, yd = eng.to_device(batch), eng.alloc(12 * N), eng.alloc(4 * N)
+        eng.negative_sample_device(bd, n, rate, 17, xd, yd)
+        X, Y = xd.download(np.int32, (N, 3)), yd.download(np.float32, (N,))
+        eng.decoder_loss_backward_device(xd, yd, N, 0.01)                    # tiled order
+        tiled = (eng.loss(), eng.dcodes(), eng.get_grad("W_relation"))
+        x2 = eng.to_device(X)                                                # the same rows, not known to be tiled
+        eng.decoder_loss_backward_device(x2, yd, N, 0.01)
+        plain = (eng.loss(), eng.dcodes(), eng.get_grad("W_relation"))
+        for b in (bd, xd, yd, x2):
+            b.free()
+    finally:
+        eng.close()
+    assert np.array_equal(X[:n], batch) and (Y[:n] == 1).all() and not Y[n:].any()
+    oloss, odcodes, odwrel = oracle.distmult_loss_and_grads(codes, params["W_relation"], X, Y, 0.01)
+    for loss, dcodes, dwrel in (tiled, plain):
+        assert abs(loss - oloss) <= 2e-5 * max(1.0, abs(oloss))
+        assert_close(dcodes, odcodes, rel=2e-4, name="dcodes")
+        assert_close(dwrel, odwrel, rel=2e-4, name="dW_relation")
+    assert np.array_equal(tiled[1], plain[1])              # the entity gradient does not depend on the relation order
+    assert_close(tiled[2], plain[2], rel=2e-6, name="dW_relation tiled vs plain")
+
+
 def numpy_clip_adam(params, grads, names, lr, b1, b2, eps, max_norm, steps_state):
     gn = np.sqrt(sum(float(np.sum(grads[n].astype(np.float64) ** 2)) for n in names))
     scale = max_norm / max(gn, max_norm)
