@@ -25,28 +25,24 @@ with np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")) as z:
         triples = np.ascontiguousarray(z["fb237_minibatch"].astype(np.int32))
         pool = z["fb237_valid_test"].astype(np.int32)
         batch = np.concatenate([triples, pool[rng.choice(len(pool), 15000, replace=False)]])
-neg = np.tile(batch, (10, 1))
-side = rng.rand(len(neg)) < 0.5
-rnd = rng.randint(0, V, len(neg))
-neg[side, 2] = rnd[side]
-neg[~side, 0] = rnd[~side]
-X = np.ascontiguousarray(np.concatenate([batch, neg]).astype(np.int32))
-Y = np.concatenate([np.ones(len(batch)), np.zeros(len(neg))]).astype(np.float32)
+batch = np.ascontiguousarray(batch.astype(np.int32))
+N = len(batch) * 11                      # NegativeSampleRate 10: drawn on the device, as the driver does
 params = init_encoder_params(V, R, d, L, "block", nb, rng=np.random.RandomState(1))
 params["W_relation"] = np.random.RandomState(2).randn(V, d).astype(np.float32)
 eng = _native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E)
 eng.set_params(params)
-eng.decoder_reserve(len(X))
+eng.decoder_reserve(N)
 eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
-T, Xd, Yd = eng.to_device(triples), eng.to_device(X), eng.to_device(Y)
+T, Bd, Xd, Yd = eng.to_device(triples), eng.to_device(batch), eng.alloc(12 * N), eng.alloc(4 * N)
+eng.negative_sample_device(Bd, len(batch), 10, 5, Xd, Yd)
 for i in range(steps):
-    eng.train_step_device(T, E, Xd, Yd, len(X), seed=i, reg_param=0.01)
+    eng.train_step_device(T, E, Xd, Yd, N, seed=i, reg_param=0.01)
 eng.sync()
 eng.timer_start()
 for i in range(steps):
-    eng.train_step_device(T, E, Xd, Yd, len(X), seed=100 + i, reg_param=0.01)
+    eng.train_step_device(T, E, Xd, Yd, N, seed=100 + i, reg_param=0.01)
 ms = eng.timer_stop()
-print("train step: %.3f ms (N = %d, E_g = %d), loss %.4f" % (ms / steps, len(X), E, eng.loss()))
-for b in (T, Xd, Yd):
+print("train step: %.3f ms (N = %d, E_g = %d), loss %.4f" % (ms / steps, N, E, eng.loss()))
+for b in (T, Bd, Xd, Yd):
     b.free()
 eng.close()
