@@ -134,14 +134,16 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_test_collective(force=False):
+def build_test_collective(force=False, device_side=False):
     """tests/collective_double/shm_collective.hip -> its _build/libshmcollective.so: the shared-memory stand-in
     for librccl that tests/test_gpu_multiprocess.py binds through RGCN_RCCL_LIBRARY (test infrastructure; host
-    code only, compiled here so that the prebuilt .so travels to the GPU box with the tree)."""
+    code only, compiled here so that the prebuilt .so travels to the GPU box with the tree).  device_side=True:
+    ipc_collective.hip -> libipccollective.so, the stand-in whose collectives are kernels (capturable)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "tests", "collective_double", "shm_collective.hip")
+    name = "ipc_collective" if device_side else "shm_collective"
+    src = os.path.join(root, "tests", "collective_double", name + ".hip")
     outdir = os.path.join(root, "tests", "collective_double", "_build")
-    out = os.path.join(outdir, "libshmcollective.so")
+    out = os.path.join(outdir, "lib%s.so" % name.replace("_", ""))
     stamp = out + ".sha"
     dig = _digest([src])
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:

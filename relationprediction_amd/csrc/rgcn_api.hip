@@ -1327,12 +1327,11 @@ rgcn_status rgcn_capture_begin(rgcn_ctx* c) {
   RGCN_NEED(c);
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "a capture is already running");
   if (c->prof_on) RGCN_FAIL(c, RGCN_ERR_STATE, "switch the per-kernel profile off before capturing");
-  // Sharded contexts: the step contains RCCL collectives.  RCCL can be stream-captured, but that path cannot be
-  // exercised on the one-GPU development box (the test collective synchronises on the host), so it is opt-in:
-  // RGCN_CAPTURE_SHARDED=1 records the collectives into the graph like any other launch.
-  if (c->world > 1 && !(getenv("RGCN_CAPTURE_SHARDED") && atoi(getenv("RGCN_CAPTURE_SHARDED")) == 1))
-    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "capture on a sharded context is opt-in (RGCN_CAPTURE_SHARDED=1): the RCCL "
-                                       "collectives inside a captured step are untested on this build");
+  // Sharded contexts: the step contains RCCL collectives, which a stream capture records like any other launch
+  // (exercised by tests/test_gpu_multiprocess.py::test_captured_sharded_train_step with device-side collectives of
+  // several ranks on one GPU; RGCN_CAPTURE_SHARDED=0 refuses instead).
+  if (c->world > 1 && getenv("RGCN_CAPTURE_SHARDED") && atoi(getenv("RGCN_CAPTURE_SHARDED")) == 0)
+    RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "capture on a sharded context is switched off (RGCN_CAPTURE_SHARDED=0)");
   RGCN_TRY(sync_all(c));
   if (!c->replay_counter) {
     RGCN_HIP(c, hipMalloc((void**)&c->replay_counter, sizeof(uint64_t)));

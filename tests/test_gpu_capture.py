@@ -193,15 +193,23 @@ def test_config5_fb15k_train_step_in_a_hipgraph(native):
             e.close()
 
 
-def test_capture_on_a_sharded_context_is_refused_by_default(native):
-    """BASELINE config 5 asks for a captured train step on 8 GPUs; the collectives inside such a step cannot be
-    exercised on the one-GPU box (the test collective synchronises on the host), so the library refuses unless
-    RGCN_CAPTURE_SHARDED=1 -- loudly, with RGCN_ERR_UNSUPPORTED, instead of capturing something it never ran"""
+def test_capture_on_a_sharded_context_needs_its_communicator(native):
+    """BASELINE config 5 asks for a captured train step on 8 GPUs.  Capture on a world > 1 context is allowed (the
+    collectives inside the graph are exercised by test_gpu_multiprocess.py::test_captured_sharded_train_step); a step
+    without a communicator still fails inside the capture as it does outside, and the capture can be ended."""
     eng = native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2)
     try:
+        tri = eng.to_device(np.array([[0, 1, 2], [3, 0, 4]], dtype=np.int32))
+        dc = eng.to_device(np.zeros((40, 8), dtype=np.float32))
+        eng.capture_begin()
         with pytest.raises(native.RgcnError) as err:
-            eng.capture_begin()
-        assert "RGCN_CAPTURE_SHARDED" in str(err.value)
+            eng.step_device(tri, 2, dc, train=True, seed=1)
+        assert "rgcn_comm_init" in str(err.value)
+        try:
+            eng.graph_destroy(eng.capture_end())
+        except native.RgcnError:
+            pass                                   # an empty / failed capture may be refused: the context stays usable
+        tri.free(); dc.free()
     finally:
         eng.close()
 

@@ -41,6 +41,24 @@ def test_sharded_steps_across_processes(collective, world, kind, nb):
     assert "SHARDED-OK world=%d kind=%s" % (world, kind) in r.stdout
 
 
+@pytest.fixture(scope="module")
+def device_collective():
+    from relationprediction_amd import build
+    return build.build_test_collective(device_side=True)
+
+
+@pytest.mark.parametrize("world,kind,nb", [(2, "block", 8), (3, "block", 8), (2, "basis", 2)])
+def test_captured_sharded_train_step(device_collective, world, kind, nb):
+    """BASELINE.json configs[4] as written -- a hipGraph-captured train step on a relation-sharded context -- with the
+    collectives INSIDE the graph (the device-side stand-in of tests/collective_double/ipc_collective.hip: kernels and
+    hipIpc mailboxes, no host synchronisation): replays equal the directly issued steps bitwise, on every rank."""
+    r = launch(world, 29700 + world + (10 if kind == "basis" else 0),
+               [os.path.join(DOUBLE, "captured_worker.py"), kind, str(nb)], device_collective,
+               {"RGCN_CAPTURE_SHARDED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=180)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "elastic" not in l and "torch/distributed" not in l)[-4000:]
+    assert "CAPTURED-SHARDED-OK world=%d kind=%s" % (world, kind) in r.stdout
+
+
 def check_multi_rank_line(r, world):
     assert r.returncode == 0, r.stdout[-2000:] + "\n".join(l for l in r.stderr.splitlines() if "elastic" not in l and "torch/distributed" not in l)[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
