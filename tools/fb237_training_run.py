@@ -8,7 +8,7 @@ reference, so the absolute MRR is not comparable with the paper's; the run shows
 sampler, device negatives, fused train step, device ranking, early stopping, checkpoints) working and learning at
 full size, and what one iteration costs under the driver.
 
-    python tools/fb237_training_run.py [iterations]         (default 4000)
+    python tools/fb237_training_run.py [iterations] [driver flags, e.g. --host-sampler]        (default 4000)
 """
 import os
 import sys
@@ -92,7 +92,7 @@ def main():
         f.write(SETTINGS % os.path.join(tmp, "models", "GcnBlock"))
     np.random.seed(0)
     t0 = time.time()
-    model, n = train.main(["--settings", settings, "--dataset", data, "--max-iterations", str(iters)])
+    model, n = train.main(["--settings", settings, "--dataset", data, "--max-iterations", str(iters)] + sys.argv[2:])
     wall = time.time() - t0
     print("%d iterations in %.1f s = %.2f ms / iteration, everything included (dataset load, engine creation, "
           "%d validation + test evaluations of 2,000 triples each, both sides, filtered)"
