@@ -22,16 +22,17 @@
 // (rgcn_neighborhood_reserve: union-find, adjacency CSR); per draw the host evaluates the V vertex priorities (a
 // counter-based hash: ~40 us), which settles the component order, the boundary component, its start vertex and r; the
 // device does the rest -- pull-style Bellman-Ford sweeps over the adjacency (one wavefront per 256-entry segment of a
-// vertex's list: d(v) = min over incident edges of d(other) + X[other,e]), pick times, a radix select of the r-th smallest (12-bit
-// digits, LDS histograms), a stable compaction -- a function of the seed alone, one replayed hipGraph, a few hundred
-// microseconds on the prefetch stream beside the running train step, no batch built on the host, nothing uploaded but
-// the 48-byte parameter block (and a byte per component when more than one component takes part).
+// vertex's list: d(v) = min over incident edges of d(other) + X[other,e]), pick times, a radix select of the r-th
+// smallest (12-bit digits, LDS histograms), a stable compaction -- a function of the seed alone, one replayed hipGraph,
+// a few hundred microseconds on the prefetch stream beside the running train step, no batch built on the host, nothing
+// uploaded but the 48-byte parameter block (and a byte per component when more than one component takes part).
 // tests/test_gpu_sampler.py holds the distribution of the drawn sets to oracle.sample_edge_neighborhood (the
 // reference's loop, step for step) on graphs with several components, self loops and parallel edges.
 //
-// The sweeps stop by themselves: launch i returns at once when launch i-1 moved nothing; the budget (64 launches, 208 sweeps = hops of
-// the deepest shortest path; the 272,115-edge training graph settles in ~20 launches) covers small-world graphs several times over, and a graph that
-// exhausts it raises the context's error flag instead of returning a wrong batch (the driver keeps the host sampler).
+// The sweeps stop by themselves: launch i returns at once when launch i-1 moved nothing; the budget (64 launches, 208
+// sweeps = hops of the deepest shortest path; the 272,115-edge training graph settles in ~20 launches) covers
+// small-world graphs several times over, and a graph that exhausts it raises the context's error flag instead of
+// returning a wrong batch (train.py --host-sampler is the way out for such a graph).
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
