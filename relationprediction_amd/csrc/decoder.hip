@@ -783,8 +783,6 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
       if (T == 1) RGCN_LAUNCH_ER(1, 1); else if (T == 2) RGCN_LAUNCH_ER(1, 2); else RGCN_LAUNCH_ER(1, 4);
     }
 #undef RGCN_LAUNCH_ER
-    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.max_chunks, Nt, d, reg_param,
-                       q.loss);
   } else {
     ProfScope ps(c, "dec_energy", 12.0 * N * d + 20.0 * N, 6.0 * N * d, 4.0 * d * ((double)V + R) + 20.0 * N);
     if (vec4)
@@ -793,8 +791,27 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     else
       hipLaunchKernelGGL((k_dec_energy<1>), dim3(q.energy_blocks), dim3(256), 0, c->stream, codes, Wr, q.X, Y, N, Nt, V,
                          R, d, q.dx, q.loss_part);
-    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, q.energy_blocks, Nt, d, reg_param,
-                       q.loss);
+  }
+  {
+    // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
+    // beside the entity gradient (forked right behind the energy kernel) and the encoder's backward pass (the caller
+    // joins it: stream_join(c, 2))
+    StreamScope side(c, 2);
+    // the loss itself (one workgroup summing the kernel's partials) is nobody's input on the device: it goes there too
+    hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, fused ? q.max_chunks : q.energy_blocks,
+                       Nt, d, reg_param, q.loss);
+    ProfScope ps(c, "dec_relation_grad", fused ? 4.0 * q.max_chunks * d + 8.0 * R * d : 8.0 * N * d + 8.0 * R * d,
+                 fused ? 0.0 : 3.0 * N * d);
+    if (fused) {
+      // the chunk partials are already in the slab (k_dec_energy_rel)
+    } else if (vec4)
+      hipLaunchKernelGGL((k_dec_rel_partial<4>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
+                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
+    else
+      hipLaunchKernelGGL((k_dec_rel_partial<1>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
+                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
+    hipLaunchKernelGGL(k_dec_rel_reduce, dim3((R * d + 255) / 256), dim3(256), 0, c->stream, q.slab, q.chunk_ptr,
+                       q.rel_ptr, Wr, gWr, R, d, k);
   }
   {
     EntArgs a;
@@ -825,23 +842,6 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
 #undef RGCN_LAUNCH_EG
     if (vec4) hipLaunchKernelGGL((k_dec_long_finish<4>), dim3(128), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_dec_long_finish<1>), dim3(128), dim3(256), 0, c->stream, a);
-  }
-  {
-    // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
-    // beside the entity gradient and the encoder's backward pass (the caller joins it: stream_join(c, 2))
-    StreamScope side(c, 2);
-    ProfScope ps(c, "dec_relation_grad", fused ? 4.0 * q.max_chunks * d + 8.0 * R * d : 8.0 * N * d + 8.0 * R * d,
-                 fused ? 0.0 : 3.0 * N * d);
-    if (fused) {
-      // the chunk partials are already in the slab (k_dec_energy_rel)
-    } else if (vec4)
-      hipLaunchKernelGGL((k_dec_rel_partial<4>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
-                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
-    else
-      hipLaunchKernelGGL((k_dec_rel_partial<1>), dim3(q.max_chunks), dim3(kRowThreads), 0, c->stream, codes, q.dx,
-                         q.X, q.permr, q.rel_ptr, q.chunk_ptr, R, d, q.slab);
-    hipLaunchKernelGGL(k_dec_rel_reduce, dim3((R * d + 255) / 256), dim3(256), 0, c->stream, q.slab, q.chunk_ptr,
-                       q.rel_ptr, Wr, gWr, R, d, k);
   }
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
