@@ -29,10 +29,11 @@
 // tests/test_gpu_sampler.py holds the distribution of the drawn sets to oracle.sample_edge_neighborhood (the
 // reference's loop, step for step) on graphs with several components, self loops and parallel edges.
 //
-// The sweeps stop by themselves: launch i returns at once when launch i-1 moved nothing; the budget (64 launches, 208
-// sweeps = hops of the deepest shortest path; the 272,115-edge training graph settles in ~20 launches) covers
-// small-world graphs several times over, and a graph that exhausts it raises the context's error flag instead of
-// returning a wrong batch (train.py --host-sampler is the way out for such a graph).
+// The sweeps stop by themselves: launch i returns at once when launch i-1 moved nothing; the budget (sized at
+// rgcn_neighborhood_reserve from the graph's diameter: 64 launches = 208 sweeps for a small world -- the 272,115-edge
+// training graph settles in ~20 launches --, up to 1,024 launches for a graph thousands of hops across) covers the hops
+// of the deepest shortest path several times over, and a graph that still exhausts it raises the context's error flag
+// instead of returning a wrong batch (train.py --host-sampler is the way out for such a graph).
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
@@ -43,7 +44,7 @@ namespace rgcn {
 
 namespace {
 
-constexpr int kSweepLaunches = 64, kSegment = 256;
+constexpr int kSweepLaunches = 64, kMaxSweepLaunches = 1024, kSegment = 256;   // launches: floor and ceiling of the budget
 // sweeps per launch: the early launches move most vertices (stop test after 2), the tail trickles (4 per launch)
 constexpr int kEarlyLaunches = 24, kEarlySweeps = 2, kLateSweeps = 4;
 // "something moved" flags: kFlagSlots per launch, each in its own 128-byte line -- sixteen thousand wavefronts storing
@@ -393,6 +394,45 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   q.comp_edges_h.assign((size_t)q.ncomp, 0);
   for (int e = 0; e < n; ++e) q.comp_edges_h[q.comp_h[tri[3 * e]]]++;
   q.comp_state_h.assign((size_t)q.ncomp, 0);
+  // The sweep budget follows the graph: a shortest path of the percolation has a few times as many hops as the graph
+  // distance it spans, so the budget is 12 x (largest component diameter, by a double breadth-first sweep per
+  // component) + 64 sweeps, at least the 208 of kSweepLaunches launches, at most kMaxSweepLaunches launches.
+  {
+    std::vector<int32_t> depth((size_t)V, -1), queue;
+    queue.reserve((size_t)V);
+    auto bfs = [&](int src, int& far) {
+      queue.clear();
+      queue.push_back(src);
+      depth[src] = 0;
+      far = src;
+      for (size_t h = 0; h < queue.size(); ++h) {
+        const int v = queue[h];
+        for (int j = ptr[v]; j < ptr[v + 1]; ++j) {
+          const int u = other[j];
+          if (depth[u] < 0) { depth[u] = depth[v] + 1; queue.push_back(u); far = u; }
+        }
+      }
+      const int ecc = depth[far];
+      for (int v : queue) depth[v] = -1;
+      return ecc;
+    };
+    std::vector<uint8_t> done((size_t)q.ncomp, 0);
+    int diameter = 0;
+    for (int v = 0; v < V; ++v) {
+      const int cid = q.comp_h[v];
+      if (cid < 0 || done[cid]) continue;
+      done[cid] = 1;
+      int far = v, far2 = v;
+      (void)bfs(v, far);
+      diameter = std::max(diameter, bfs(far, far2));
+    }
+    const int64_t sweeps = std::max<int64_t>(kEarlyLaunches * kEarlySweeps + (kSweepLaunches - kEarlyLaunches) * kLateSweeps,
+                                            12 * (int64_t)diameter + 64);
+    const int64_t launches = kEarlyLaunches + (sweeps - kEarlyLaunches * kEarlySweeps + kLateSweeps - 1) / kLateSweeps;
+    q.launches = (int32_t)std::min<int64_t>(kMaxSweepLaunches, std::max<int64_t>(kSweepLaunches, launches));
+    if (const char* e = getenv("RGCN_NBR_LAUNCHES"))     // a smaller budget, for measuring how many launches a graph needs
+      q.launches = std::min(q.launches, std::max(atoi(e), 1));
+  }
   const size_t nb = (size_t)((n + kCompactBlock - 1) / kCompactBlock) + 1;
   RGCN_TRY(dalloc(c, &q.triples, 3 * (size_t)n));
   RGCN_TRY(dalloc(c, &q.seg_v, seg_v.size()));
@@ -406,7 +446,7 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   RGCN_TRY(dalloc(c, &q.tkey, (size_t)n));
   RGCN_TRY(dalloc(c, &q.hist, (size_t)kBins));
   RGCN_TRY(dalloc(c, &q.state, (size_t)2));
-  RGCN_TRY(dalloc(c, &q.changed, (size_t)kSweepLaunches * kFlagSlots * kFlagStride));
+  RGCN_TRY(dalloc(c, &q.changed, (size_t)q.launches * kFlagSlots * kFlagStride));
   RGCN_TRY(dalloc(c, &q.bcnt, nb));
   RGCN_HIP(c, hipMalloc(&q.params, sizeof(DrawParams)));
   hipStream_t st = c->stream;
@@ -429,14 +469,11 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
 static rgcn_status record_draw(rgcn_ctx* c) {
   NeighborhoodBufs& q = c->nbr;
   const int n = (int)q.n, V = c->V, T = 256;
-  static const int launches = [] {              // RGCN_NBR_LAUNCHES: a smaller budget, for measuring how many a graph needs
-    const char* e = getenv("RGCN_NBR_LAUNCHES");
-    return e ? std::min(std::max(atoi(e), 1), kSweepLaunches) : kSweepLaunches;
-  }();
+  const int launches = q.launches;
   if (!q.capture_stream) RGCN_HIP(c, hipStreamCreateWithFlags(&q.capture_stream, hipStreamNonBlocking));
   hipStream_t st = q.capture_stream;
   const DrawParams* p = reinterpret_cast<const DrawParams*>(q.params);
-  const int nflags = kSweepLaunches * kFlagSlots * kFlagStride;
+  const int nflags = launches * kFlagSlots * kFlagStride;
   const dim3 ge((unsigned)((n + T - 1) / T)), gw((unsigned)(((size_t)std::max(q.nseg, 1) * 64 + T - 1) / T)), bt(T);
   const dim3 gi((unsigned)((std::max(V, nflags) + T - 1) / T));
   RGCN_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));

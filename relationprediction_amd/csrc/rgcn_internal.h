@@ -235,6 +235,7 @@ struct NeighborhoodBufs {
   int32_t *adj_other = nullptr, *adj_end = nullptr;
   int32_t *seg_v = nullptr, *seg_beg = nullptr, *seg_end = nullptr;     // segments of <= 256 entries of one vertex's list
   int32_t nseg = 0;
+  int32_t launches = 64;                 // sweep launches of one draw (from the graph's diameter, at reserve)
   int32_t* comp = nullptr;               // [V] connected component of the vertex (-1: no edges)
   uint8_t* comp_state = nullptr;         // [ncomp] 1: every edge of the component is in the batch (device copy)
   uint32_t* dist = nullptr;              // [V] touched-time (bits of a non-negative float)

@@ -172,3 +172,28 @@ def test_training_graph_scale(native):
     touched = np.unique(rows[:, [0, 2]])
     assert len({find(v) for v in touched}) == 1
     assert ms < 5.0
+
+
+def test_a_graph_a_thousand_hops_across(native):
+    """A chain of 1,200 vertices (diameter 1,199): the sweep budget is sized from the graph's diameter when the graph is
+    handed over, so the relaxations settle where a fixed small-world budget would refuse.  On a chain the reference's
+    process grows an interval, to the left or to the right with equal probability: every batch is 500 consecutive
+    edges, and the interval's left end has the distribution of the reference's loop (mean over 150 draws each)."""
+    V, k, n = 1200, 500, 150
+    triples = np.stack([np.arange(V - 1), np.zeros(V - 1, dtype=np.int64), np.arange(1, V)], 1).astype(np.int32)
+    with native.Engine(V, 1, 4, 1, "block", 1, max_edges=V) as eng:
+        eng.neighborhood_reserve(triples)
+        buf = native.DeviceBuffer(eng, 12 * k)
+        try:
+            lefts = []
+            for seed in range(n):
+                rows = draw(native, eng, buf, k, 31 + seed)
+                assert np.array_equal(rows[:, 2], rows[:, 0] + 1)                      # rows of the chain
+                assert np.array_equal(rows[:, 0], np.arange(rows[0, 0], rows[0, 0] + k))   # consecutive: one interval
+                lefts.append(int(rows[0, 0]))
+        finally:
+            buf.free()
+    rng = np.random.RandomState(2)
+    ref = [int(np.min(oracle.sample_edge_neighborhood(triples, V, k, rng))) for _ in range(n)]
+    se = np.sqrt((np.var(lefts) + np.var(ref)) / n)
+    assert abs(np.mean(lefts) - np.mean(ref)) <= 4.5 * se, (np.mean(lefts), np.mean(ref), se)
