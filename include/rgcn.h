@@ -229,8 +229,8 @@ rgcn_status rgcn_sampler_edge_neighborhood(rgcn_sampler* sampler, int64_t sample
  * batch_out_dev, asynchronously on the main stream or -- on_prefetch_stream != 0 -- on the stream
  * rgcn_prefetch_graph*_device works on, so that "draw the next batch, drop edges, prepare its graph" runs beside the
  * current step.  sample_size above the number of training triples is an error; a graph whose sweeps do not
- * settle within the budget (shortest paths of more than ~100 hops) is refused at the next synchronising call, never
- * answered wrongly. */
+ * settle within the budget (sized at rgcn_neighborhood_reserve from the graph's diameter; graphs several thousand hops
+ * across exceed its ceiling) is refused at the next synchronising call, never answered wrongly. */
 rgcn_status rgcn_neighborhood_reserve(rgcn_ctx* ctx, const int32_t* triples_host, int64_t num_triples);
 rgcn_status rgcn_sample_neighborhood_device(rgcn_ctx* ctx, int64_t sample_size, uint64_t seed, int32_t* batch_out_dev,
                                             int32_t on_prefetch_stream);
