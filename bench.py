@@ -123,6 +123,9 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra workload")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-oracle steps (0 disables)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes that measure the headline workload's HBM bytes per launch in "
+                         "this run (the committed profiles/*_traffic.json figures are reported instead)")
     ap.add_argument("--no-fp32-reference", action="store_true",
                     help="skip the extra timed run with the dense contractions on the fp32 MFMA (rocprofv3 passes)")
     ap.add_argument("--hipgraph", action="store_true",
@@ -159,8 +162,11 @@ KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "
 
 
 def traffic_table(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*traffic*.json,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be collected from inside the process"""
+    """HBM bytes per launch: measured in this run for the headline workload (measure_live_traffic: counters cannot be
+    collected from inside the process, so the script runs itself twice under rocprofv3 --pmc), else from the committed
+    rocprofv3 PMC passes of this same command (profiles/*traffic*.json, FETCH_SIZE doubled per MI355X_MICROARCH.md)"""
+    if workload in LIVE_TRAFFIC:
+        return LIVE_TRAFFIC[workload]
     try:
         pick = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_%s_serial_traffic.json" % workload)))
         if pick:
@@ -168,6 +174,64 @@ def traffic_table(workload):
     except Exception:  # noqa: BLE001
         pass
     return {}, None
+
+
+LIVE_TRAFFIC = {}      # workload -> (kernel name -> bytes per launch, source text): filled by measure_live_traffic
+
+
+def measure_live_traffic(workload, args):
+    """HBM bytes per launch of every kernel of `workload`, measured in THIS run: two extra passes of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: counters only, one counter per pass, as MI355X_MICROARCH.md prescribes;
+    no trace domains), a few steps each on one stream; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (gfx950 FETCH_SIZE
+    half-count correction).  Any failure (no rocprofv3, a pass that times out) leaves the committed figures in force."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return False
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "4", "--warmup", "2", "--cpu-steps", "0",
+           "--no-kernel-profile", "--no-extra-workloads", "--no-fp32-reference", "--no-live-traffic", "--gemm-mode",
+           str(args.gemm_mode)]
+    env = dict(os.environ, TMPDIR="/tmp", RGCN_STREAMS="0", RGCN_BENCH_PREFETCH="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+
+    def short(name):
+        return re.sub(r"\(.*", "", name.replace("rgcn::(anonymous namespace)::", "").replace("void ", ""))
+    per = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                r = subprocess.run([prof, "--pmc", counter, "-d", out, "-o", "p", "--"] + cmd, cwd="/tmp", env=env,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                db = os.path.join(out, "p_results.db")
+                if r.returncode != 0 or not os.path.exists(db):
+                    hits = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+                    if not hits:
+                        return False
+                    db = hits[0]
+                rows = sqlite3.connect(db).execute("select kernel_name, count(*), sum(value) from counters_collection "
+                                                   "where counter_name=? group by kernel_name", (counter,)).fetchall()
+                acc = {}
+                for name, n, tot in rows:
+                    a = acc.setdefault(short(name), [0, 0.0])
+                    a[0] += n
+                    a[1] += tot
+                per[counter] = {k: v[1] / max(v[0], 1) for k, v in acc.items()}
+    except Exception:  # noqa: BLE001
+        return False
+    fetch, write = per.get("FETCH_SIZE", {}), per.get("WRITE_SIZE", {})
+    kernels = {k: (2 * fetch[k] + write[k]) * 1024 for k in fetch if k in write}
+    if not kernels:
+        return False
+    LIVE_TRAFFIC[workload] = (kernels, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each of `bench.py "
+                                       "--workload %s --steps 4 --warmup 2` on one stream; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024"
+                              % workload)
+    return True
 
 
 def kernel_table(prof, steps, args, in_pipeline=None):
@@ -880,6 +944,8 @@ def main():
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
         import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
 
+    if rk.world == 1 and not args.no_live_traffic and not args.no_kernel_profile:
+        measure_live_traffic(args.workload, args)
     out = measure(args.workload, args, rk, args.steps, args.warmup, full=True)
     extras = []
     widen = rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph

@@ -109,6 +109,10 @@ def test_bench_single_gpu_line_carries_every_section():
     assert d["config"]["norm_mode"].startswith("intended")
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "compulsory_bytes", "design_bytes"} <= set(d["roofline"])
     assert 0 < d["roofline"]["frac"] <= 1
+    # HBM bytes per launch: measured in this run (two rocprofv3 --pmc passes of the script itself), or -- when rocprofv3
+    # is missing or a pass fails -- the committed figures
+    src = d["roofline"]["traffic_source"]
+    assert d["roofline"]["traffic"] > 0 and (src.startswith("measured in this run") or src.startswith("profiles/")), src
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
     assert d["cpu_baseline_reference_code"]["kind"].startswith("reference-code") \
         and d["cpu_baseline_reference_code"]["measured_in_this_run"] is False
