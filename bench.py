@@ -192,6 +192,10 @@ def measure_live_traffic(workload, args):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return False
+    # already running under a profiler (someone wrapped this script in rocprofv3 / set a tools library): do not nest
+    if any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) or k == "HSA_TOOLS_LIB" for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return False
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "4", "--warmup", "2", "--cpu-steps", "0",
            "--no-kernel-profile", "--no-extra-workloads", "--no-fp32-reference", "--no-live-traffic", "--gemm-mode",
            str(args.gemm_mode)]
@@ -207,7 +211,7 @@ def measure_live_traffic(workload, args):
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 out = os.path.join(tmp, counter)
                 r = subprocess.run([prof, "--pmc", counter, "-d", out, "-o", "p", "--"] + cmd, cwd="/tmp", env=env,
-                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=75)
                 db = os.path.join(out, "p_results.db")
                 if r.returncode != 0 or not os.path.exists(db):
                     hits = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
