@@ -238,6 +238,29 @@ def measure_live_traffic(workload, args):
     return True
 
 
+def apply_live_traffic(out, args):
+    """AFTER every timed region of the run (two profiler passes just before one cost the headline 3 % on the same box):
+    measure the headline workload's HBM bytes per launch and put them where the committed figures stood."""
+    if not out.get("kernels") or not measure_live_traffic(out["config"]["workload"], args):
+        return
+    traffic, src = LIVE_TRAFFIC[out["config"]["workload"]]
+    for k in out["kernels"]:
+        pref = KERNEL_OF_TAG.get(k["kernel"])
+        if pref and pref.startswith("k_gemm") and args.gemm_mode == 0:
+            pref = None
+        k["traffic"] = next((round(v) for n, v in traffic.items() if pref and n.startswith(pref)), None)
+    if out.get("roofline"):
+        top = next((k for k in out["kernels"] if k["kernel"] == out["roofline"]["kernel"]), None)
+        if top is not None:
+            out["roofline"]["traffic"] = top["traffic"]
+            out["roofline"]["traffic_source"] = src
+    sr = out.get("step_roofline")
+    if sr:
+        sr["pmc_bytes_per_step"] = sum(k["traffic"] * k["launches_per_step"] for k in out["kernels"] if k["traffic"]) or None
+        sr["pmc_missing_kernels"] = [k["kernel"] for k in out["kernels"] if k["traffic"] is None
+                                     and not k["kernel"].startswith("rccl_") and k["ms_per_step"] >= 0.002]
+
+
 def kernel_table(prof, steps, args, in_pipeline=None):
     """rgcn_profile_get rows -> per-kernel accounting: exclusive average duration and, per launch, three byte counts --
     compulsory (every distinct input byte once + every output byte once), design (what the launch site asks
@@ -948,8 +971,6 @@ def main():
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
         import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
 
-    if rk.world == 1 and not args.no_live_traffic and not args.no_kernel_profile:
-        measure_live_traffic(args.workload, args)
     out = measure(args.workload, args, rk, args.steps, args.warmup, full=True)
     extras = []
     widen = rk.world == 1 and args.workload == "fb237_block" and not args.no_extra_workloads and not args.hipgraph
@@ -966,6 +987,8 @@ def main():
     evaluation = measure_evaluation(args) if widen else None
     train_loop = (measure_train_loop(args, train_steps[0]["minibatch_step"]["ms_per_step"],
                                      iterations=max(20, 6 * args.extra_steps)) if widen else None)
+    if rk.rank == 0 and rk.world == 1 and not args.no_live_traffic and not args.no_kernel_profile:
+        apply_live_traffic(out, args)
     if rk.rank == 0:
         out["workloads"] = extras
         out["train_steps"] = train_steps
