@@ -270,6 +270,7 @@ static void free_all(rgcn_ctx* c) {
   for (hipGraphExec_t g : c->graphs) if (g) (void)hipGraphExecDestroy(g);
   for (hipGraph_t g : c->graph_defs) if (g) (void)hipGraphDestroy(g);
   if (c->replay_counter) (void)hipFree(c->replay_counter);
+  if (c->readback_host) (void)hipHostFree(c->readback_host);
   if (c->stage_host) {
     (void)hipHostFree(c->stage_host);
     for (hipEvent_t e : c->stage_done) if (e) (void)hipEventDestroy(e);
@@ -1082,8 +1083,18 @@ rgcn_status rgcn_get_loss(rgcn_ctx* c, double* loss) {
   RGCN_NEED(c);
   if (!loss) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL output");
   if (!c->dec.loss_valid) RGCN_FAIL(c, RGCN_ERR_STATE, "no decoder pass has run");
-  RGCN_TRY(check_dev_flag(c, /*main_only=*/true));
-  return to_host(c, loss, c->dec.loss, sizeof(double));
+  if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
+  // the training loop reads the loss every iteration (optimize.py:81-88 returns it from session.run): the loss and the
+  // device-side error flag come back through pinned memory with ONE wait for the main stream
+  if (!c->readback_host) RGCN_HIP(c, hipHostMalloc((void**)&c->readback_host, 32, hipHostMallocDefault));
+  double* h_loss = reinterpret_cast<double*>(c->readback_host);
+  int32_t* h_flag = reinterpret_cast<int32_t*>(c->readback_host + 16);
+  RGCN_HIP(c, hipMemcpyAsync(h_flag, c->g.errflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->main_stream));
+  RGCN_HIP(c, hipMemcpyAsync(h_loss, c->dec.loss, sizeof(double), hipMemcpyDeviceToHost, c->main_stream));
+  RGCN_HIP(c, hipStreamSynchronize(c->main_stream));
+  if (*h_flag) RGCN_TRY(check_dev_flag(c, /*main_only=*/true));      // reads it again, clears it, names the failure
+  *loss = *h_loss;
+  return RGCN_OK;
 }
 
 rgcn_status rgcn_negative_sample_device(rgcn_ctx* c, const int32_t* batch_dev, int64_t n, int32_t rate, uint64_t seed,

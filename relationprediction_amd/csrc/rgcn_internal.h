@@ -330,6 +330,7 @@ struct rgcn_ctx {
   static constexpr int kStageSlots = 8;
   static constexpr size_t kStageBytes = (size_t)1 << 20;
   uint8_t* stage_host = nullptr;         // kStageSlots * kStageBytes, hipHostMalloc
+  uint8_t* readback_host = nullptr;      // 32 pinned bytes: rgcn_get_loss fetches the loss and the error flag with one wait
   hipEvent_t stage_done[kStageSlots] = {};
   int stage_next = 0;
   bool chunk_fixed = false;              // RGCN_CHUNK in the environment pins the chunk size
