@@ -30,8 +30,8 @@
 // reference's loop, step for step) on graphs with several components, self loops and parallel edges.
 //
 // The sweeps stop by themselves: launch i returns at once when launch i-1 moved nothing; the budget (sized at
-// rgcn_neighborhood_reserve from the graph's diameter: 64 launches = 208 sweeps for a small world -- the 272,115-edge
-// training graph settles in ~20 launches --, up to 1,024 launches for a graph thousands of hops across) covers the hops
+// rgcn_neighborhood_reserve from the graph's diameter: 48 launches = 104 sweeps for a small world -- the 272,115-edge
+// training graph settles in 23-26 --, up to 1,024 launches = 4,008 sweeps for a graph thousands of hops across) covers the hops
 // of the deepest shortest path several times over, and a graph that still exhausts it raises the context's error flag
 // instead of returning a wrong batch (train.py --host-sampler is the way out for such a graph).
 #include <algorithm>
@@ -44,9 +44,16 @@ namespace rgcn {
 
 namespace {
 
-constexpr int kSweepLaunches = 64, kMaxSweepLaunches = 1024, kSegment = 256;   // launches: floor and ceiling of the budget
-// sweeps per launch: the early launches move most vertices (stop test after 2), the tail trickles (4 per launch)
-constexpr int kEarlyLaunches = 24, kEarlySweeps = 2, kLateSweeps = 4;
+constexpr int kSweepLaunches = 48, kMaxSweepLaunches = 1024, kSegment = 256;   // launches: floor and ceiling of the budget
+// Sweeps per launch.  What a launch's wavefronts store reaches the others' plain loads at the NEXT launch, so a second
+// sweep inside a launch mostly repeats the first (measured: two sweeps per launch settled the training graph in 19-20
+// launches, ONE sweep per launch in 23-26 -- the same hops, half the work): one sweep per launch while distances still
+// move everywhere, more per launch (coherent loads from the second on) only in the tail that deep graphs need.
+__host__ __device__ constexpr int sweeps_of_launch(int it) { return it < 24 ? 1 : (it < 32 ? 2 : 4); }
+constexpr int64_t sweeps_of_budget(int launches) {
+  return (launches < 24 ? launches : 24) + 2 * (launches < 24 ? 0 : (launches < 32 ? launches - 24 : 8)) +
+         4 * (int64_t)(launches < 32 ? 0 : launches - 32);
+}
 // "something moved" flags: kFlagSlots per launch, each in its own 128-byte line -- sixteen thousand wavefronts storing
 // to ONE address serialise in the L2 (it was 30 of the 43 us of an early sweep)
 constexpr int kFlagSlots = 16, kFlagStride = 32;
@@ -395,8 +402,8 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
   for (int e = 0; e < n; ++e) q.comp_edges_h[q.comp_h[tri[3 * e]]]++;
   q.comp_state_h.assign((size_t)q.ncomp, 0);
   // The sweep budget follows the graph: a shortest path of the percolation has a few times as many hops as the graph
-  // distance it spans, so the budget is 12 x (largest component diameter, by a double breadth-first sweep per
-  // component) + 64 sweeps, at least the 208 of kSweepLaunches launches, at most kMaxSweepLaunches launches.
+  // distance it spans (3.5 times on the training graph), so the budget is 12 x (largest component diameter, by a double
+  // breadth-first sweep per component) + 32 sweeps, at least kSweepLaunches launches, at most kMaxSweepLaunches.
   {
     std::vector<int32_t> depth((size_t)V, -1), queue;
     queue.reserve((size_t)V);
@@ -426,10 +433,10 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
       (void)bfs(v, far);
       diameter = std::max(diameter, bfs(far, far2));
     }
-    const int64_t sweeps = std::max<int64_t>(kEarlyLaunches * kEarlySweeps + (kSweepLaunches - kEarlyLaunches) * kLateSweeps,
-                                            12 * (int64_t)diameter + 64);
-    const int64_t launches = kEarlyLaunches + (sweeps - kEarlyLaunches * kEarlySweeps + kLateSweeps - 1) / kLateSweeps;
-    q.launches = (int32_t)std::min<int64_t>(kMaxSweepLaunches, std::max<int64_t>(kSweepLaunches, launches));
+    const int64_t sweeps = 12 * (int64_t)diameter + 32;
+    int launches = kSweepLaunches;
+    while (launches < kMaxSweepLaunches && sweeps_of_budget(launches) < sweeps) ++launches;
+    q.launches = launches;
     if (const char* e = getenv("RGCN_NBR_LAUNCHES"))     // a smaller budget, for measuring how many launches a graph needs
       q.launches = std::min(q.launches, std::max(atoi(e), 1));
   }
@@ -480,7 +487,7 @@ static rgcn_status record_draw(rgcn_ctx* c) {
   hipLaunchKernelGGL(k_nbr_init, gi, bt, 0, st, p, q.dist, V, q.changed, nflags);
   for (int it = 0; it < launches; ++it)
     hipLaunchKernelGGL(k_nbr_sweep, gw, bt, 0, st, p, q.seg_v, q.seg_beg, q.seg_end, q.nseg, q.adj_other, q.adj_end, q.dist,
-                       q.changed, it, it < kEarlyLaunches ? kEarlySweeps : kLateSweeps);
+                       q.changed, it, sweeps_of_launch(it));
   hipLaunchKernelGGL(k_nbr_check, dim3(1), dim3(64), 0, st, q.changed, launches - 1, c->g.errflag);
   hipLaunchKernelGGL(k_nbr_keys, ge, bt, 0, st, p, q.triples, n, q.comp, q.dist, q.tkey);
   SelState* state = reinterpret_cast<SelState*>(q.state);
