@@ -54,8 +54,8 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_
 }
 
 // ---- CSR construction -----------------------------------------------------------------------
-__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, uint32_t rel_mul, uint32_t period,
-                           uint32_t* keyv, uint32_t* keyr, int32_t* errflag) {
+__global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, int n_rel, uint32_t* keyv,
+                           uint32_t* keyr, int32_t* errflag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * N) return;
   const bool subj = i < N;
@@ -64,14 +64,37 @@ __global__ void k_dec_keys(const int32_t* __restrict__ X, int N, int V, int R, u
   const bool ok = (unsigned)s < (unsigned)V && (unsigned)o < (unsigned)V && (unsigned)r < (unsigned)R;
   if (subj && !ok) atomicOr(errflag, 2);
   keyv[i] = ok ? (uint32_t)(subj ? s : o) : (uint32_t)V;
-  // rel_mul > 1: a tiled batch (DecoderBufs::tiled_period) -- within a relation, the copies of one triple side by side
-  if (subj) keyr[n] = ok ? (uint32_t)r * rel_mul + ((uint32_t)n % period) % rel_mul : (uint32_t)R * rel_mul;
+  // n_rel < N: a tiled batch -- only the first copy of every triple is sorted by relation, k_dec_expand puts the others
+  // behind it
+  if (subj && n < n_rel) keyr[n] = ok ? (uint32_t)r : (uint32_t)R;
+}
+
+// A batch the negative sampler tiled (rows p, p + period, p + 2 period, ... are copies of row p with one entity
+// replaced): the relation order of all N triples follows from the order of the first `period` -- the copies of a triple
+// directly behind it, which is also what lets a relation chunk fetch their shared rows once.  A copy that is not what
+// the sampler wrote (another relation, an id out of range: someone rewrote the buffer) raises flag 16 and is replaced by
+// its first copy, so that the kernels behind this one stay inside their arrays.
+__global__ void k_dec_expand(const int32_t* __restrict__ X, int N, int V, int R, int period, int L,
+                             const int32_t* __restrict__ perm_pos, int32_t* __restrict__ permr, int32_t* errflag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int g = i / L, j = i - g * L;
+  const int p = perm_pos[g];
+  int t = p + j * period;
+  if (j > 0) {
+    const int s = X[3 * t], r = X[3 * t + 1], o = X[3 * t + 2];
+    if (r != X[3 * p + 1] || (unsigned)s >= (unsigned)V || (unsigned)o >= (unsigned)V) {
+      atomicOr(errflag, 16);
+      t = p;
+    }
+  }
+  permr[i] = t;
 }
 
 // block 0: relation offsets + exclusive scan of the chunk counts; blocks 1..: entity row offsets + long rows
 __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ keyv_s,
                                                    const uint32_t* __restrict__ keyr_s, int N, int V, int R,
-                                                   uint32_t rel_mul, int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
+                                                   int n_rel, int rel_scale, int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
                                                    int32_t* long_first, int32_t* long_cnt, int32_t* piece_row,
                                                    int32_t* piece_k, int piece_cap, int32_t* rel_ptr,
                                                    int32_t* chunk_ptr) {
@@ -85,9 +108,9 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
       const int r = base + tid;
       int lo = 0, nchunks = 0;
       if (r <= R) {
-        lo = lower_bound_u32(keyr_s, N, (uint32_t)r * rel_mul);
+        lo = lower_bound_u32(keyr_s, n_rel, (uint32_t)r) * rel_scale;
         rel_ptr[r] = lo;
-        if (r < R) nchunks = (lower_bound_u32(keyr_s, N, (uint32_t)(r + 1) * rel_mul) - lo + kDecChunk - 1) / kDecChunk;
+        if (r < R) nchunks = (lower_bound_u32(keyr_s, n_rel, (uint32_t)(r + 1)) * rel_scale - lo + kDecChunk - 1) / kDecChunk;
       }
       int incl = nchunks;
 #pragma unroll
@@ -665,7 +688,7 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.keyv, 2 * N)); RGCN_TRY(dalloc(c, &q.keyv_s, 2 * N));
   RGCN_TRY(dalloc(c, &q.valv, 2 * N)); RGCN_TRY(dalloc(c, &q.permv, 2 * N));
   RGCN_TRY(dalloc(c, &q.keyr, N)); RGCN_TRY(dalloc(c, &q.keyr_s, N));
-  RGCN_TRY(dalloc(c, &q.valr, N)); RGCN_TRY(dalloc(c, &q.permr, N));
+  RGCN_TRY(dalloc(c, &q.valr, N)); RGCN_TRY(dalloc(c, &q.permr, N)); RGCN_TRY(dalloc(c, &q.perm_pos, N));
   RGCN_TRY(dalloc(c, &q.row_ptr, V + 1)); RGCN_TRY(dalloc(c, &q.rel_ptr, R + 1)); RGCN_TRY(dalloc(c, &q.chunk_ptr, R + 1));
   RGCN_TRY(dalloc(c, &q.e_other, 2 * N)); RGCN_TRY(dalloc(c, &q.e_rel, 2 * N)); RGCN_TRY(dalloc(c, &q.e_trip, 2 * N));
   q.long_cap = (int32_t)(2 * N / kDecLongRow + 1);
@@ -696,7 +719,7 @@ void decoder_free(rgcn_ctx* c) {
   void* ptrs[] = {q.keyv, q.keyv_s, q.valv, q.permv, q.keyr, q.keyr_s, q.valr, q.permr, q.row_ptr, q.rel_ptr,
                   q.chunk_ptr, q.e_other, q.e_rel, q.e_trip, q.long_rows, q.nlong, q.dx, q.loss_part, q.loss,
                   q.slab, q.keyv_t, q.keyr_t, q.tablev, q.tabler, q.long_first, q.long_cnt, q.piece_row, q.piece_k,
-                  q.piece_slab};
+                  q.piece_slab, q.perm_pos};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (q.ev_ready) (void)hipEventDestroy(q.ev_ready);
@@ -711,34 +734,37 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t 
   q.N = N;
   q.N_total = N_total > 0 ? N_total : N64;
   q.X = X;
-  // a batch the negative sampler tiled: relation sort by (relation, row mod period), if the key fits 32 bits
+  // a batch the negative sampler tiled (DecoderBufs::tiled_X): sort its first `period` triples by relation and expand
   static const bool tiled_order = !(getenv("RGCN_DEC_TILED") && atoi(getenv("RGCN_DEC_TILED")) == 0);
-  // (sort keys are below 2^24, csr_sort.hip: when (R + 1) * period is not, triples fall into as many buckets per
-  // relation as fit -- two triples of one relation rarely share one)
-  q.rel_mul = 1;
-  uint32_t period = 1;
-  if (tiled_order && X == q.tiled_X && N64 == q.tiled_N && (N_total <= 0 || N_total == N64) && q.tiled_period > 1 && q.tiled_period < (1 << 30)) {
-    period = (uint32_t)q.tiled_period;
-    q.rel_mul = std::max<uint32_t>(1u, std::min<uint32_t>(period, ((1u << 24) - 1u) / (uint32_t)(R + 1)));
+  int period = 0, copies = 1;
+  if (tiled_order && X == q.tiled_X && N64 == q.tiled_N && (N_total <= 0 || N_total == N64) && q.tiled_period > 1 &&
+      N64 % q.tiled_period == 0) {
+    period = (int)q.tiled_period;
+    copies = (int)(N64 / q.tiled_period);
   }
+  const int n_rel = period > 0 ? period : N;
   RGCN_HIP(c, hipMemsetAsync(q.nlong, 0, 2 * sizeof(int32_t), c->stream));
   const int T = 256;
   if (N > 0) {
     {
       ProfScope ps(c, "dec_keys", 36.0 * N, 0);
-      hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, q.rel_mul, period, q.keyv,
-                         q.keyr, c->g.errflag);
+      hipLaunchKernelGGL(k_dec_keys, dim3((2 * N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, n_rel, q.keyv, q.keyr,
+                         c->g.errflag);
     }
-    // entity incidences (2N, by entity) and triples (N, by relation): one call, shared launches
+    // entity incidences (2N, by entity) and triples (N, or their first copies, by relation): one call, shared launches
     SortSpec sp[2];
     sp[0] = SortSpec{q.keyv, q.keyv_s, q.permv, q.keyv_t, q.valv, nullptr, q.tablev, (int64_t)2 * N, (uint32_t)V};
-    sp[1] = SortSpec{q.keyr, q.keyr_s, q.permr, q.keyr_t, q.valr, nullptr, q.tabler, (int64_t)N, (uint32_t)R * q.rel_mul};
+    sp[1] = SortSpec{q.keyr, q.keyr_s, period > 0 ? q.perm_pos : q.permr, q.keyr_t, q.valr, nullptr, q.tabler,
+                     (int64_t)n_rel, (uint32_t)R};
     RGCN_TRY(sort_pairs(c, "dec_sort", 2, sp));
+    if (period > 0)
+      hipLaunchKernelGGL(k_dec_expand, dim3((N + T - 1) / T), dim3(T), 0, c->stream, X, N, V, R, period, copies, q.perm_pos,
+                         q.permr, c->g.errflag);
   }
   {
     ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);
     hipLaunchKernelGGL(k_dec_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, q.keyv_s, q.keyr_s, N,
-                       V, R, q.rel_mul, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
+                       V, R, n_rel, copies, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
                        q.piece_k, q.piece_cap, q.rel_ptr, q.chunk_ptr);
   }
   if (N > 0) {

@@ -153,6 +153,8 @@ static rgcn_status check_dev_flag(rgcn_ctx* c, bool main_only = false) {
     RGCN_FAIL(c, RGCN_ERR_INVALID, std::string(flag & 4 ? "edge dropout: the keep mask does not hold exactly `keep` ones; " : "") +
                                    (flag & 8 ? "device neighbourhood sampler: the relaxations did not settle within their iteration budget "
                                                "(a graph of very large diameter: use the host sampler); " : "") +
+                                   (flag & 16 ? "the decoder batch is no longer the tiled batch rgcn_negative_sample_device wrote into that "
+                                                "buffer (rewritten by the caller's own kernels?): pass it in another buffer; " : "") +
                                    (flag & 3 ? "graph_edges / the decoder batch contains a vertex id outside [0,EntityCount) or a "
                                                "relation id outside [0,RelationCount)" : ""));
   }
@@ -162,6 +164,12 @@ static rgcn_status check_dev_flag(rgcn_ctx* c, bool main_only = false) {
 // A caller that rewrites (or frees) the triple buffer a prefetched graph was prepared from makes that
 // preparation stale: drop it, the next step rebuilds in line.
 static void invalidate_prefetch_of(rgcn_ctx* c, const void* dev, size_t bytes) {
+  // a caller that rewrites the buffer the negative sampler tiled makes the decoder's knowledge of its layout stale
+  if (c->dec.tiled_X) {
+    const char* t = reinterpret_cast<const char*>(c->dec.tiled_X);
+    const char* lo = reinterpret_cast<const char*>(dev);
+    if (t + sizeof(int32_t) * 3 * (size_t)c->dec.tiled_N > lo && t < lo + (bytes ? bytes : 1)) c->dec.tiled_X = nullptr;
+  }
   for (GraphBufs* g : {&c->g, &c->g_alt}) {
     if (!g->pf_valid || !g->pf_tri) continue;
     const char* t = reinterpret_cast<const char*>(g->pf_tri);

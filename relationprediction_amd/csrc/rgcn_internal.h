@@ -203,11 +203,12 @@ struct DecoderBufs {
   int64_t N_total = 0;         // triples of the whole batch when N is one rank's slice of it (denominator of the means)
   // the last batch rgcn_negative_sample_device (or the fused minibatch step) wrote: `tiled_period` rows tiled rate + 1
   // times into tiled_X -- rows p, p + period, p + 2 period, ... differ from row p in ONE entity.  decoder_prepare sorts
-  // such a batch by (relation, p): the copies of a triple sit next to each other in a relation chunk and their shared
-  // rows are fetched from HBM once instead of rate + 1 times.  Only an ORDER: any batch is summed correctly under it.
+  // only the first copies by relation and puts the others directly behind them (k_dec_expand): a third of the sort work,
+  // and the copies of a triple sit next to each other in a relation chunk, their shared rows fetched from HBM once
+  // instead of rate + 1 times.  The expansion checks that every copy still has its first copy's relation (flag 16).
   const int32_t* tiled_X = nullptr;
   int64_t tiled_period = 0, tiled_N = 0;
-  uint32_t rel_mul = 1;        // relation sort key = relation * rel_mul + (row mod rel_mul)
+  int32_t* perm_pos = nullptr; // first copies in relation order
   const int32_t* X = nullptr;
   uint32_t *keyv = nullptr, *keyv_s = nullptr, *keyr = nullptr, *keyr_s = nullptr;
   int32_t *valv = nullptr, *permv = nullptr, *valr = nullptr, *permr = nullptr;

@@ -70,9 +70,10 @@ def test_device_decoder_matches_oracle(native, V, R, d, nb, E, hub):
 @pytest.mark.parametrize("V,R,n,rate", [(300, 7, 900, 10), (1400, 1345, 13000, 1)])
 def test_decoder_on_a_tiled_batch(native, V, R, n, rate):
     """A batch the device negative sampler tiled (NegativeSampler.transform's layout) is sorted by (relation, row mod
-    batch size), so that the copies of a triple share their row fetches in a relation chunk -- another ORDER of the same
-    sums: loss and gradients against the oracle, and against the untiled order (the same rows in a buffer the sampler
-    did not write); R = 1,345 with n = 13,000 exceeds the 24-bit sort key, where triples fall into buckets per relation."""
+    batch size) -- only its first copies are sorted, the others are put directly behind them -- so that the copies of a
+    triple share their row fetches in a relation chunk: another ORDER of the same sums.  Loss and gradients against the
+    oracle, and against the untiled order (the same rows in a buffer the sampler did not write); R = 1,345 with n = 13,000
+    is the FB15k-sized case."""
     d, L, nb, E = 20, 1, 4, 200
     params, triples, masks, _ = make_case(V, R, d, L, "block", nb, E, seed=3)
     rng = np.random.RandomState(8)
@@ -105,6 +106,52 @@ def test_decoder_on_a_tiled_batch(native, V, R, n, rate):
         assert_close(dwrel, odwrel, rel=2e-4, name="dW_relation")
     assert np.array_equal(tiled[1], plain[1])              # the entity gradient does not depend on the relation order
     assert_close(tiled[2], plain[2], rel=2e-6, name="dW_relation tiled vs plain")
+
+
+def test_tiled_batch_rewritten_behind_the_library(native):
+    """The decoder orders a batch the device negative sampler tiled by its first copies alone.  Rewriting that buffer
+    THROUGH the library (rgcn_copy_to_device) drops that knowledge -- the batch is sorted like any other and decoded
+    correctly; rewriting it behind the library's back (here: another context's copy into the same allocation) with a
+    copy whose relation differs from its first copy's is reported, not decoded wrongly."""
+    V, R, d, L, nb, E, n, rate = 200, 9, 20, 1, 4, 150, 300, 3
+    params, triples, masks, _ = make_case(V, R, d, L, "block", nb, E, seed=4)
+    rng = np.random.RandomState(11)
+    batch = np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1).astype(np.int32)
+    N = n * (rate + 1)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    other = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=True, masks=masks)
+        codes = eng.codes()
+        eng.decoder_reserve(N)
+        bd, xd, yd = eng.to_device(batch), eng.alloc(12 * N), eng.alloc(4 * N)
+        eng.negative_sample_device(bd, n, rate, 3, xd, yd)
+        X, Y = xd.download(np.int32, (N, 3)), yd.download(np.float32, (N,))
+        X2 = X.copy()
+        X2[n + 5, 1] = (X2[n + 5, 1] + 1) % R                    # a copy with another relation than its first copy
+        # (a) through the library: an ordinary batch again
+        eng.copy_to_device(xd, X2)
+        eng.decoder_loss_backward_device(xd, yd, N, 0.01)
+        loss, dcodes, dwrel = eng.loss(), eng.dcodes(), eng.get_grad("W_relation")
+        oloss, odcodes, odwrel = oracle.distmult_loss_and_grads(codes, params["W_relation"], X2, Y, 0.01)
+        assert abs(loss - oloss) <= 2e-5 * max(1.0, abs(oloss))
+        assert_close(dcodes, odcodes, rel=2e-4, name="dcodes")
+        assert_close(dwrel, odwrel, rel=2e-4, name="dW_relation")
+        # (b) behind its back
+        eng.negative_sample_device(bd, n, rate, 3, xd, yd)
+        other.copy_to_device(xd, X2)
+        other.sync()
+        eng.decoder_loss_backward_device(xd, yd, N, 0.01)
+        with pytest.raises(native.RgcnError) as err:
+            eng.loss()
+        assert "tiled batch" in str(err.value)
+        for b in (bd, xd, yd):
+            b.free()
+    finally:
+        other.close()
+        eng.close()
 
 
 def numpy_clip_adam(params, grads, names, lr, b1, b2, eps, max_norm, steps_state):
