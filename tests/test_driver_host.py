@@ -377,3 +377,46 @@ print("aliases ok")
 ''' % root
     r = subprocess.run([_sys.executable, "-B", "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "aliases ok" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_device_sampled_batches_are_drawn_one_iteration_ahead(tmp_path):
+    """The loop's order of calls for device-sampled minibatches (optimize.HipOptimizer.fit): step i is enqueued, then
+    batch i + 1 is staged (its graph prepared beside the step), then batch i + 2 is drawn (presample), then the loss of
+    step i is read -- every batch staged once, drawn ahead at most once, stepped once, in request order; the last
+    iterations stage / draw nothing that does not exist."""
+    class Recorder(FakeTrainModel):
+        def __init__(self, losses):
+            FakeTrainModel.__init__(self, losses)
+            self.log = []
+
+        def device_train_step_minibatch(self, mb, seed):
+            self.steps.append(mb)
+            self.log.append(("step", mb.sample[2]))
+
+        def device_stage(self, *a):
+            raise AssertionError("minibatches are staged through device_stage_minibatch")
+
+        def device_stage_minibatch(self, mb):
+            self.log.append(("stage", mb.sample[2]))
+
+        def device_presample_minibatch(self, mb):
+            self.log.append(("draw", mb.sample[2]))
+
+        def device_loss(self):
+            self.log.append(("loss", self.steps[-1].sample[2]))
+            return FakeTrainModel.device_loss(self)
+
+    opp = optimizer_parameter_parser.Parser(reference_settings(tmp_path, extra="\tMaxIterations=5"))
+    model = Recorder(losses=[1.0] * 10)
+    opp.set_early_stopping_score_function(lambda data: 1.0)
+    opp.set_save_function(model.save)
+    counter = iter(range(100))
+    train = object()
+    opp.set_sample_transform_function(
+        lambda x: optimize.DeviceMinibatch(None, 10, 0, 2, sample=(train, 20, next(counter))))
+    assert optimize.build_hip(model, opp.get_parametrization()).fit([0]) == 5
+    assert model.log == [("step", 0), ("stage", 1), ("draw", 2), ("loss", 0),
+                         ("step", 1), ("stage", 2), ("draw", 3), ("loss", 1),
+                         ("step", 2), ("stage", 3), ("draw", 4), ("loss", 2),
+                         ("step", 3), ("stage", 4), ("loss", 3),
+                         ("step", 4), ("loss", 4)]
