@@ -881,8 +881,17 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RGCN_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # a rank that never comes back (a collective one peer never joined) must not hold the caller for ever: after
+    # RGCN_BENCH_TIMEOUT seconds (default 900) the ranks are killed -- these exact processes -- and the run fails
+    limit = float(os.environ.get("RGCN_BENCH_TIMEOUT", "900"))
+    try:
+        out0, _ = procs[0].communicate(timeout=limit)
+        rcs = [procs[0].returncode] + [q.wait(timeout=60) for q in procs[1:]]
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        sys.exit("bench.py --gpus %d: no result after %.0f s, ranks killed" % (n, limit))
     sys.stdout.write(out0)
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
@@ -968,6 +977,17 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
     rk = Ranks(args)
+    if rk.world > 1:
+        # launched by torch.distributed.run (or by spawn_ranks above): a watchdog of its own, for the same reason
+        import threading
+
+        def give_up():
+            sys.stderr.write("bench.py rank %d: no result after %s s, giving up\n" % (rk.rank, os.environ.get("RGCN_BENCH_TIMEOUT", "900")))
+            sys.stderr.flush()
+            os._exit(124)
+        dog = threading.Timer(float(os.environ.get("RGCN_BENCH_TIMEOUT", "900")), give_up)
+        dog.daemon = True
+        dog.start()
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
         import torch  # noqa: F401  (test knob: exercise a torch-first load order on one GPU)
 
