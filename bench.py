@@ -717,11 +717,12 @@ TRAIN_LOOP_SETTINGS = """[Encoder]
 def measure_train_loop(args, device_step_ms, iterations=150, workers=(0, 8)):
     """The reference's WHOLE training iteration (code/train.py:161-247 + optimization/optimize.py:81-88) through this
     repository's driver, at settings/gcn_block.exp's values on the 272,115-edge synthetic FB15k-237 training graph: the
-    neighbourhood edge sampler (30,000 picks, the reference's random process, on the HOST: librgcn.so's O(log V)
-    sampler), upload of the graph batch, then ONE device call (edge dropout + negatives + prep + encoder + DistMult +
-    clip + Adam) and the loss read back every iteration, as the reference's loop does.  Reported: ms per iteration with
-    the batches built in line and by k background threads, the host's cost of building one batch, and the fraction of
-    the iteration the device is idle -- row f4 of SURVEY 8 measured instead of asserted."""
+    neighbourhood edge sampler (30,000 picks), then ONE device call (edge dropout + negatives + prep + encoder + DistMult
+    + clip + Adam) and the loss read back every iteration, as the reference's loop does -- with the sampler on the DEVICE
+    (csrc/neighborhood.hip, the driver's default: no batch built on the host, nothing uploaded) and with the host
+    sampler (librgcn.so's O(log V) port of the reference's process + upload of the graph batch) building batches in line
+    and on k background threads.  Reported: ms per iteration of each form, the host's cost of building one batch, and
+    the fraction of the iteration the device is idle -- row f4 of SURVEY 8 measured instead of asserted."""
     import contextlib
     import tempfile
     import numpy as np
