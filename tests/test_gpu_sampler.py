@@ -197,3 +197,48 @@ def test_a_graph_a_thousand_hops_across(native):
     ref = [int(np.min(oracle.sample_edge_neighborhood(triples, V, k, rng))) for _ in range(n)]
     se = np.sqrt((np.var(lefts) + np.var(ref)) / n)
     assert abs(np.mean(lefts) - np.mean(ref)) <= 4.5 * se, (np.mean(lefts), np.mean(ref), se)
+
+
+def test_thousands_of_components_against_the_host_sampler(native):
+    """The 10,000 real WN18 valid+test triples: 3,914 components, the largest 482 edges.  A batch of 5,000 edges there is
+    ~950 whole components and a piece of one more -- the restart rule at scale.  Touched vertices, components present
+    and components taken in full over 40 draws, against the HOST sampler (the reference's process pick for pick, held
+    draw for draw to the reference by tests/test_reference_fixtures.py): means within 4.5 standard errors."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with np.load(os.path.join(root, "tests", "golden", "graphs.npz")) as z:
+        triples = np.ascontiguousarray(z["wn18_valid_test"].astype(np.int32))
+    V, k, n = 40943, 5000, 40
+    parent = np.arange(V)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for s, _, o in triples:
+        a, b = find(s), find(o)
+        if a != b:
+            parent[max(a, b)] = min(a, b)
+    comp = np.array([find(v) for v in range(V)])
+    comp_edges = np.bincount(comp[triples[:, 0]], minlength=V)
+
+    def stats(t):
+        got = np.bincount(comp[t[:, 0]], minlength=V)
+        return len(np.unique(t[:, [0, 2]])), int((got > 0).sum()), int(((got > 0) & (got == comp_edges)).sum())
+    with native.Engine(V, 18, 4, 1, "block", 1, max_edges=k) as eng:
+        eng.neighborhood_reserve(triples)
+        buf = native.DeviceBuffer(eng, 12 * k)
+        try:
+            dev = [stats(draw(native, eng, buf, k, 900 + i)) for i in range(n)]
+        finally:
+            buf.free()
+    host = native.NeighborhoodSampler(triples, V)
+    ref = [stats(triples[host.sample(k, 4000 + i)]) for i in range(n)]
+    host.close()
+    dev, ref = np.array(dev, dtype=np.float64), np.array(ref, dtype=np.float64)
+    assert (ref[:, 2] > 500).all() and (ref[:, 1] - ref[:, 2] <= 1).all()      # whole components + at most one piece
+    assert (dev[:, 1] - dev[:, 2] <= 1).all()
+    for j in range(3):
+        se = np.sqrt((dev[:, j].var() + ref[:, j].var()) / n) + 1e-9
+        assert abs(dev[:, j].mean() - ref[:, j].mean()) <= 4.5 * se, (j, dev[:, j].mean(), ref[:, j].mean(), se)
