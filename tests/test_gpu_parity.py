@@ -699,3 +699,72 @@ def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
             eng.forward(train=False)
             res.append(eng.codes())
     np.testing.assert_array_equal(res[0], res[1])
+
+
+def test_training_graph_scale_properties(native):
+    """BASELINE's largest graph on one GPU -- the 272,115-edge FB15k-237 training-graph shape (hub rows of more than ten
+    thousand messages: the giant-row path) at d = 500, 100 blocks -- where the numpy oracle's [E, nb, sd, sd] gathers do
+    not fit: size-independent properties instead.
+    (1) A checksum of checksums, one layer, test mode: every message lands at exactly one vertex, so the column sums of
+        (codes - self-loop product) equal  sum_r T_f[r] (sum_{e in r} n_f[e] H[s_e]) + sum_r T_b[r] (sum_{e in r} n_b[e] H[o_e]),
+        computed in float64 with one sparse product per direction.
+    (2) The backward pass is linear in the upstream gradient (two layers, train mode, the same dropout seed): every
+        gradient of 0.7 dY1 - 1.3 dY2 equals 0.7 grad(dY1) - 1.3 grad(dY2)."""
+    import importlib.util
+    import os
+    import scipy.sparse as sp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_graph2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    triples = bench.load_graph("synth:fb237_valid_test:272115")
+    V, R, d, nb, E = 14541, 237, 500, 100, len(triples)
+    sd = d // nb
+    s, r, o = oracle.split_graph(triples)
+    # ---- (1)
+    rng = np.random.RandomState(3)
+    params = oracle.init_params(V, R, d, 1, "block", nb, rng=rng)
+    params["b_emb"] = (rng.randn(d) * 0.01).astype(np.float32)
+    eng = native.Engine(V, R, d, 1, "block", nb, max_edges=E)
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        codes = eng.codes().astype(np.float64)
+        selfp = eng.read_buffer(native.BUF_SELF).astype(np.float64)
+    finally:
+        eng.close()
+    H0 = oracle.affine_onehot_forward(params["W_emb"], params["b_emb"]).astype(np.float64)
+    n_f = oracle.incidence_values(o, V, "intended").astype(np.float64)
+    n_b = oracle.incidence_values(s, V, "intended").astype(np.float64)
+    S_f = sp.coo_matrix((n_f, (r, s)), shape=(R, V)).tocsr() @ H0            # [R, d]
+    S_b = sp.coo_matrix((n_b, (r, o)), shape=(R, V)).tocsr() @ H0
+    want = (np.einsum("rbij,rbj->bi", params["W_f1"].astype(np.float64), S_f.reshape(R, nb, sd)) +
+            np.einsum("rbij,rbj->bi", params["W_b1"].astype(np.float64), S_b.reshape(R, nb, sd))).reshape(d)
+    msgs = codes - selfp
+    got, scale = msgs.sum(0), np.abs(msgs).sum(0)
+    assert np.isfinite(codes).all() and float(np.abs(got - want).max() / scale.max()) <= 2e-6, \
+        float(np.abs(got - want).max() / scale.max())
+    # ---- (2)
+    params = oracle.init_params(V, R, d, 2, "block", nb, rng=rng)
+    dy1 = (rng.randn(V, d) * 0.01).astype(np.float32)
+    dy2 = (rng.randn(V, d) * 0.01).astype(np.float32)
+    eng = native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=E)
+    try:
+        eng.set_params(params)
+        tri_dev = eng.to_device(triples)
+        grads = []
+        for dy in (dy1, dy2, (0.7 * dy1 - 1.3 * dy2).astype(np.float32)):
+            dc = eng.to_device(dy)
+            eng.step_device(tri_dev, E, dc, train=True, seed=21)
+            grads.append({k: v.astype(np.float64) for k, v in eng.get_grads().items() if v is not None})
+            dc.free()
+        tri_dev.free()
+    finally:
+        eng.close()
+    for k in grads[0]:
+        if k == "W_relation" or not grads[0][k].size:
+            continue
+        lin = 0.7 * grads[0][k] - 1.3 * grads[1][k]
+        sc = max(float(np.abs(grads[0][k]).max()), float(np.abs(grads[1][k]).max()), 1e-30)
+        assert float(np.abs(grads[2][k] - lin).max()) <= 2e-5 * sc, (k, float(np.abs(grads[2][k] - lin).max()), sc)
