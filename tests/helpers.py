@@ -173,3 +173,29 @@ def error_against(ref64, got):
     if scale == 0.0:
         return (float(np.abs(g).max()) if g.size else 0.0), 0.0
     return float(np.abs(g - r).max()) / scale, float(np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()))
+
+
+def chunked_distmult_float64(codes, w_rel, X, Y, reg, chunk=20000):
+    """oracle.distmult_loss_and_grads (bilinear_diag.py:14-34,63-69) in float64, chunk by chunk and with sparse products
+    for the two scatter-adds, so that N = 330,000 x d = 500 fits: the same formulas, nothing [N, d] held at once."""
+    import scipy.sparse as sp
+    V, d = codes.shape
+    N = len(X)
+    c64, w64 = codes.astype(np.float64), w_rel.astype(np.float64)
+    xent = sq = 0.0
+    dcodes, drel = np.zeros((V, d)), np.zeros(w_rel.shape)
+    for lo in range(0, N, chunk):
+        x = X[lo:lo + chunk]
+        y = Y[lo:lo + chunk].astype(np.float64)
+        e1, rr, e2 = c64[x[:, 0]], w64[x[:, 1]], c64[x[:, 2]]
+        en = (e1 * rr * e2).sum(1)
+        xent += float(((1 - y) * en + np.log1p(np.exp(-np.abs(en))) + np.maximum(-en, 0)).sum())
+        sq += float((e1 ** 2).sum() + (rr ** 2).sum() + (e2 ** 2).sum())
+        g = ((1.0 / (1.0 + np.exp(-en)) - y) / N)[:, None]
+        k = 2.0 * reg / (N * d)
+        n = len(x)
+        rows = np.arange(n)
+        for idx, contrib, out in ((x[:, 0], g * rr * e2 + k * e1, dcodes), (x[:, 2], g * e1 * rr + k * e2, dcodes),
+                                  (x[:, 1], g * e1 * e2 + k * rr, drel)):
+            out += sp.coo_matrix((np.ones(n), (idx, rows)), shape=(out.shape[0], n)).tocsr() @ contrib
+    return xent / N + reg * sq / (N * d), dcodes, drel

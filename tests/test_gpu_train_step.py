@@ -517,3 +517,41 @@ def test_minibatch_step_equals_the_step_on_its_own_draws(native, prefetch):
             eng.close()
     for k in out[0]:
         np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
+
+
+def test_decoder_at_baseline_scale(native):
+    """The decoder at BASELINE.json's size -- V = 14,541, d = 500, 30,000 positives x (1 + 10) = 330,000 triples drawn
+    by the device negative sampler (the tiled order, the pipelined energy kernel, hub entities cut into pieces) -- against
+    the chunked float64 restatement of the oracle (tests/helpers.py, pinned to it by tests/test_oracle_chunked.py): loss to 2e-6, every entry of dL/dcodes and dL/dW_relation within 5e-6 of scale."""
+    import helpers
+    V, R, d, L, nb, rate = 14541, 237, 500, 1, 100, 10
+    graph = helpers.load_graph("fb237_minibatch")
+    pool = helpers.load_graph("fb237_valid_test")
+    rng = np.random.RandomState(12)
+    batch = np.ascontiguousarray(np.concatenate([graph, pool[rng.choice(len(pool), 15000, replace=False)]]).astype(np.int32))
+    n = len(batch)
+    N = n * (rate + 1)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    params["W_relation"] = (rng.randn(V, d) * 0.5).astype(np.float32)
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=len(graph))
+    try:
+        eng.set_params(params)
+        eng.set_graph(graph)
+        eng.forward(train=False)
+        codes = eng.codes()
+        eng.decoder_reserve(N)
+        bd, xd, yd = eng.to_device(batch), eng.alloc(12 * N), eng.alloc(4 * N)
+        eng.negative_sample_device(bd, n, rate, 23, xd, yd)
+        X, Y = xd.download(np.int32, (N, 3)), yd.download(np.float32, (N,))
+        eng.decoder_loss_backward_device(xd, yd, N, 0.01)
+        loss, dcodes, dwrel = eng.loss(), eng.dcodes(), eng.get_grad("W_relation")
+        for b in (bd, xd, yd):
+            b.free()
+    finally:
+        eng.close()
+    oloss, odcodes, odwrel = helpers.chunked_distmult_float64(codes, params["W_relation"], X, Y, 0.01)
+    assert abs(loss - oloss) <= 2e-6 * abs(oloss), (loss, oloss)
+    for got, want, name in ((dcodes, odcodes, "dcodes"), (dwrel, odwrel, "dW_relation")):
+        err = float(np.abs(got.astype(np.float64) - want).max())
+        assert err <= 5e-6 * float(np.abs(want).max()), (name, err, float(np.abs(want).max()))
+    assert not dwrel[R:].any()
