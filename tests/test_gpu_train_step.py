@@ -555,3 +555,52 @@ def test_decoder_at_baseline_scale(native):
         err = float(np.abs(got.astype(np.float64) - want).max())
         assert err <= 5e-6 * float(np.abs(want).max()), (name, err, float(np.abs(want).max()))
     assert not dwrel[R:].any()
+
+
+def test_train_step_at_baseline_scale_optimizer_replay(native):
+    """One whole minibatch train step at BASELINE's sizes (V = 14,541, d = 500, 100 blocks, 30,000-edge batch with
+    exact-15,000 edge dropout, 330,000 decoder triples): the loss is finite and of the expected size, every gradient is
+    finite and non-trivial, and the device's global-norm clip + Adam update over all 10 million weights equals a numpy
+    float64 replay of tensorflow_backend/algorithms.py:27-42,58-68 from the device's own gradients -- two steps, so that
+    Adam's moments and step count carry over."""
+    import helpers
+    V, R, d, L, nb, rate, keep = 14541, 237, 500, 2, 100, 10, 15000
+    graph = helpers.load_graph("fb237_minibatch")
+    pool = helpers.load_graph("fb237_valid_test")
+    rng = np.random.RandomState(31)
+    batch = np.ascontiguousarray(np.concatenate([graph, pool[rng.choice(len(pool), 15000, replace=False)]]).astype(np.int32))
+    n = len(batch)
+    N = n * (rate + 1)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    names = [k for k in oracle.weight_names("block", L) if not (k.startswith("b") and k != "b_emb")]
+    eng = native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=n)
+    try:
+        eng.set_params(params)
+        eng.decoder_reserve(N)
+        eng.optimizer_config(lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0)
+        bd, xd, yd = eng.to_device(batch), eng.alloc(12 * N), eng.alloc(4 * N)
+        cur = {k: eng.get_param(k) for k in eng.param_names}
+        m = {k: np.zeros_like(cur[k], dtype=np.float64) for k in names}
+        v = {k: np.zeros_like(cur[k], dtype=np.float64) for k in names}
+        for step in (1, 2):
+            eng.train_step_minibatch_device(bd, n, keep, 70 + step, rate, 80 + step, xd, yd, seed=90 + step, reg_param=0.01)
+            loss = eng.loss()
+            assert np.isfinite(loss) and 0.05 < loss < 2.0, loss
+            grads = {k: eng.get_grad(k).astype(np.float64) for k in names}
+            assert all(np.isfinite(g).all() and np.abs(g).max() > 0 for g in grads.values())
+            gn = np.sqrt(sum(float((g ** 2).sum()) for g in grads.values()))
+            scale = 1.0 / max(gn, 1.0)                                   # clip_by_global_norm(max 1)
+            lr_t = 0.01 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            for k in names:
+                g = grads[k] * scale
+                m[k] = 0.9 * m[k] + 0.1 * g
+                v[k] = 0.999 * v[k] + 0.001 * g * g
+                want = cur[k].astype(np.float64) - lr_t * m[k] / (np.sqrt(v[k]) + 1e-8)
+                got = eng.get_param(k)
+                # an update is at most lr_t in size: 1e-3 of that, entry by entry (fp32 moments against float64)
+                assert float(np.abs(got - want).max()) <= 1e-3 * lr_t, (step, k, float(np.abs(got - want).max()))
+                cur[k] = got
+        for b in (bd, xd, yd):
+            b.free()
+    finally:
+        eng.close()
