@@ -199,3 +199,133 @@ def chunked_distmult_float64(codes, w_rel, X, Y, reg, chunk=20000):
                                   (x[:, 1], g * e1 * e2 + k * rr, drel)):
             out += sp.coo_matrix((np.ones(n), (idx, rows)), shape=(out.shape[0], n)).tocsr() @ contrib
     return xent / N + reg * sq / (N * d), dcodes, drel
+
+
+# ----------------------------------------------------------------------------- chunked float64 encoder (block kind)
+_CHUNK_THREADS = min(8, os.cpu_count() or 1)
+
+
+def _chunked_block_messages(H, W, rows_in, rel, rows_out, nrm, V, chunk, absolute=False):
+    """sum over the messages e of  nrm[e] * (W[rel[e]] . H[rows_in[e]])  scattered to rows_out[e]  ([V, d], float64),
+    edge chunk by edge chunk: gather W[type] ([chunk, nb, sd, sd]: gcn_basis_concat.py:38-39), the batched sd x sd
+    products (:46-47), one sparse [V, chunk] x [chunk, d] product per chunk (:73-76).  absolute = True sums |terms|
+    instead (the per-element error scale of the same sum)."""
+    import scipy.sparse as sp
+    from concurrent.futures import ThreadPoolExecutor
+    R, nb, sd, _ = W.shape
+    d = nb * sd
+    E = len(rel)
+
+    def one(lo):
+        sl = slice(lo, lo + chunk)
+        n = len(rel[sl])
+        x = H[rows_in[sl]].reshape(n, nb, sd)
+        T = W[rel[sl]]
+        if absolute:
+            m = np.einsum("ebij,ebj->ebi", np.abs(T), np.abs(x)).reshape(n, d)
+        else:
+            m = np.einsum("ebij,ebj->ebi", T, x).reshape(n, d)
+        A = sp.coo_matrix((nrm[sl], (rows_out[sl], np.arange(n))), shape=(V, n)).tocsr()
+        return A @ m
+
+    out = np.zeros((V, d))
+    with ThreadPoolExecutor(max_workers=_CHUNK_THREADS) as ex:       # numpy drops the GIL inside these calls
+        for part in ex.map(one, range(0, E, chunk)):                 # added in chunk order whatever finishes first
+            out += part
+    return out
+
+
+def chunked_block_layer_float64(params, l, L, H, triples, V, mode="train", keep=0.8, mask=None, norm_mode=None,
+                                chunk=16384, with_scale=False, return_pre=False):
+    """ONE block layer (message_gcn.py:49-79 around gcn_basis_concat.py:35-83) in float64 from the given layer input:
+    relu?( dropout(H . W_self) + A_f F + A_b K ).  with_scale: also the sum of the ABSOLUTE values of the terms of every
+    output element -- what the fp32 rounding error of that element is proportional to."""
+    norm_mode = oracle.NORM_INTENDED if norm_mode is None else norm_mode
+    s, r, o = oracle.split_graph(triples)
+    n_f = oracle.incidence_values(o, V, norm_mode).astype(np.float64)
+    n_b = oracle.incidence_values(s, V, norm_mode).astype(np.float64)
+    H = np.asarray(H, dtype=np.float64)
+    W_f, W_b = params["W_f%d" % l].astype(np.float64), params["W_b%d" % l].astype(np.float64)
+    W_self = params["W_self%d" % l].astype(np.float64)
+    S = H @ W_self
+    drop = (np.asarray(mask, dtype=np.float64) / keep) if mode == "train" else None
+    if drop is not None:
+        S = S * drop
+    # forward messages: sender s -> receiver o with W_f; backward messages: o -> s with W_b
+    pre = (_chunked_block_messages(H, W_f, s, r, o, n_f, V, chunk) +
+           _chunked_block_messages(H, W_b, o, r, s, n_b, V, chunk)) + S
+    out = pre if return_pre else (np.maximum(pre, 0.0) if l < L else pre)
+    if not with_scale:
+        return out
+    sc = (_chunked_block_messages(H, W_f, s, r, o, n_f, V, chunk, absolute=True) +
+          _chunked_block_messages(H, W_b, o, r, s, n_b, V, chunk, absolute=True))
+    Sabs = np.abs(H) @ np.abs(W_self)
+    if drop is not None:
+        Sabs = Sabs * drop
+    return out, sc + Sabs
+
+
+def chunked_block_encoder_forward_float64(params, triples, V, L, mode="train", keep=0.8, masks=None,
+                                          norm_mode=None, chunk=16384, with_scale=False):
+    """oracle.encoder_forward for the block kind (affine_transform.py:63-83, message_gcn.py:49-79,
+    gcn_basis_concat.py:35-83) in float64, never holding an [E, d] or [E, nb, sd, sd] array whole -- what the
+    272,115-edge GPU test compares with.  Returns [H0..HL] (and, with_scale, the per-element scales of every layer)."""
+    H = np.maximum(params["W_emb"].astype(np.float64) + params["b_emb"].astype(np.float64), 0.0)
+    acts, scales = [H], [np.abs(H)]
+    for l in range(1, L + 1):
+        res = chunked_block_layer_float64(params, l, L, H, triples, V, mode=mode, keep=keep,
+                                          mask=masks[l - 1] if mode == "train" else None, norm_mode=norm_mode,
+                                          chunk=chunk, with_scale=with_scale)
+        H = res[0] if with_scale else res
+        if with_scale:
+            scales.append(res[1])
+        acts.append(H)
+    return (acts, scales) if with_scale else acts
+
+
+def chunked_block_encoder_backward_float64(params, triples, V, L, acts, dcodes, mode="train", keep=0.8, masks=None,
+                                           norm_mode=None, chunk=16384):
+    """oracle.encoder_backward for the block kind (SURVEY 8a row a15 = tf.gradients of the forward above) in float64,
+    edge chunk by edge chunk, evaluated at the given activations."""
+    import scipy.sparse as sp
+    from concurrent.futures import ThreadPoolExecutor
+    norm_mode = oracle.NORM_INTENDED if norm_mode is None else norm_mode
+    s, r, o = oracle.split_graph(triples)
+    E = len(s)
+    n_f = oracle.incidence_values(o, V, norm_mode).astype(np.float64)
+    n_b = oracle.incidence_values(s, V, norm_mode).astype(np.float64)
+    acts = [np.asarray(a, dtype=np.float64) for a in acts]
+    grads = {}
+    dH = np.asarray(dcodes, dtype=np.float64)
+    for l in range(L, 0, -1):
+        W_f, W_b = params["W_f%d" % l].astype(np.float64), params["W_b%d" % l].astype(np.float64)
+        W_self = params["W_self%d" % l].astype(np.float64)
+        R, nb, sd, _ = W_f.shape
+        Hin, Hout = acts[l - 1], acts[l]
+        D = dH * (Hout > 0) if l < L else dH
+        dS = D * (np.asarray(masks[l - 1], dtype=np.float64) / keep) if mode == "train" else D
+        grads["W_self%d" % l] = Hin.T @ dS
+        dHin = dS @ W_self.T
+        gW = {"f": np.zeros((R, nb * sd * sd)), "b": np.zeros((R, nb * sd * sd))}
+        for tag, W, rows_in, rows_out, nrm in (("f", W_f, s, o, n_f), ("b", W_b, o, s, n_b)):
+            def one(lo, W=W, rows_in=rows_in, rows_out=rows_out, nrm=nrm):
+                sl = slice(lo, lo + chunk)
+                n = len(r[sl])
+                g = (D[rows_out[sl]] * nrm[sl, None]).reshape(n, nb, sd)        # dF[e] = n[e] D[receiver]
+                x = Hin[rows_in[sl]].reshape(n, nb, sd)
+                gT = np.einsum("ebi,ebj->ebij", g, x).reshape(n, nb * sd * sd)
+                dw = sp.coo_matrix((np.ones(n), (r[sl], np.arange(n))), shape=(R, n)).tocsr() @ gT
+                dx = np.einsum("ebij,ebi->ebj", W[r[sl]], g).reshape(n, nb * sd)
+                return dw, sp.coo_matrix((np.ones(n), (rows_in[sl], np.arange(n))), shape=(V, n)).tocsr() @ dx
+            with ThreadPoolExecutor(max_workers=_CHUNK_THREADS) as ex:
+                for dw, dh in ex.map(one, range(0, E, chunk)):
+                    gW[tag] += dw
+                    dHin += dh
+        grads["W_f%d" % l] = gW["f"].reshape(W_f.shape)
+        grads["W_b%d" % l] = gW["b"].reshape(W_b.shape)
+        grads["b%d" % l] = np.zeros(Hin.shape[1])
+        dH = dHin
+    g0 = dH * (acts[0] > 0)
+    grads["W_emb"] = g0
+    grads["b_emb"] = g0.sum(axis=0)
+    return grads

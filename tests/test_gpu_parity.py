@@ -768,3 +768,90 @@ def test_training_graph_scale_properties(native):
         lin = 0.7 * grads[0][k] - 1.3 * grads[1][k]
         sc = max(float(np.abs(grads[0][k]).max()), float(np.abs(grads[1][k]).max()), 1e-30)
         assert float(np.abs(grads[2][k] - lin).max()) <= 2e-5 * sc, (k, float(np.abs(grads[2][k] - lin).max()), sc)
+
+
+def test_training_graph_elementwise_parity(native):
+    """ELEMENT-WISE parity at BASELINE's largest single-GPU graph: the 272,115-edge FB15k-237 training-graph shape
+    (V = 14,541, d = 500, 100 blocks, 2 layers; 5,000+ rows on the long-row path, one row beyond the 2,048-slot giant-row
+    cut) against the edge-chunked float64 restatement of the oracle (tests/helpers.py, pinned to oracle.encoder_step on
+    the CPU by tests/test_oracle_chunked.py).  Reference: gcn_basis_concat.py:35-83, message_gcn.py:49-79,
+    model.py:59-81 (the evaluation encode is the test-mode forward pass of this graph).
+
+      * forward in test mode (= the evaluation encode) AND in train mode (the device's own dropout draw, read back):
+        every element of every layer within 1e-4 absolute of the chained float64 forward (north_star's tolerance);
+      * layer by layer from the ENGINE's own layer input: every element within 1e-5 of ITS error scale (the sum of the
+        absolute values of its terms) -- tight enough that ONE message of the giant row delivered to a neighbouring
+        vertex fails it, which the test demonstrates on a corrupted reference;
+      * every gradient of the train-mode pass against the float64 reverse mode at the engine's own activations
+        (no gate can differ): every entry within 5e-6 of its tensor's scale, 2e-6 in l2."""
+    import importlib.util
+    import os
+    from helpers import (chunked_block_encoder_forward_float64, chunked_block_encoder_backward_float64,
+                         chunked_block_layer_float64, error_against)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_graph3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    triples = bench.load_graph("synth:fb237_valid_test:272115")
+    V, R, d, nb, L, E = 14541, 237, 500, 100, 2, len(triples)
+    s, r, o = oracle.split_graph(triples)
+    slots = np.bincount(o, minlength=V) + np.bincount(s, minlength=V)
+    assert slots.max() > 2048 and (slots > 32).sum() > 1000            # the giant-row and long-row paths are in play
+    rng = np.random.RandomState(17)
+    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    params["b_emb"] = (rng.randn(d) * 0.01).astype(np.float32)
+    dcodes = (rng.randn(V, d) * 0.01).astype(np.float32)
+    with native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E) as eng:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        acts_test = [eng.activation(l) for l in range(L + 1)]
+        eng.forward(train=True, seed=5)
+        acts_train = [eng.activation(l) for l in range(L + 1)]
+        masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
+        eng.backward(dcodes)
+        grads = {k: v for k, v in eng.get_grads().items() if v is not None}
+    assert 0.78 < float(masks[0].mean()) < 0.82
+
+    def layerwise(acts, mode):
+        worst = 0.0
+        for l in range(1, L + 1):
+            ref, sc = chunked_block_layer_float64(params, l, L, acts[l - 1], triples, V, mode=mode,
+                                                  mask=masks[l - 1] if mode == "train" else None, with_scale=True)
+            ratio = np.abs(acts[l].astype(np.float64) - ref) / (sc + 1e-30)
+            worst = max(worst, float(ratio.max()))
+            assert worst <= 1e-5, (mode, l, worst, np.unravel_index(int(ratio.argmax()), ratio.shape))
+        return worst
+
+    for mode, acts in (("test", acts_test), ("train", acts_train)):
+        chained = chunked_block_encoder_forward_float64(params, triples, V, L, mode=mode, masks=masks)
+        for l in range(L + 1):
+            err = float(np.abs(acts[l].astype(np.float64) - chained[l]).max())
+            assert err <= 1e-4, (mode, l, err)
+        layerwise(acts, mode)
+
+    # ---- the check above SEES one misplaced message of the giant row: take one forward message into the giant row
+    # out of the layer-1 reference and hand it to the next vertex; the engine's (correct) output must then fail
+    vg = int(slots.argmax())
+    e = int(np.flatnonzero(o == vg)[0])
+    H0 = acts_test[0].astype(np.float64)
+    pre, sc = chunked_block_layer_float64(params, 1, L, H0, triples, V, mode="test", with_scale=True, return_pre=True)
+    n_f = float(oracle.incidence_values(o, V, oracle.NORM_INTENDED)[e])
+    m = n_f * np.einsum("bij,bj->bi", params["W_f1"][r[e]].astype(np.float64),
+                        H0[s[e]].reshape(nb, d // nb)).reshape(d)
+    wrong = pre.copy()
+    wrong[vg] -= m
+    wrong[(vg + 1) % V] += m
+    got = acts_test[1].astype(np.float64)
+    for row in (vg, (vg + 1) % V):
+        ok = np.abs(got[row] - np.maximum(pre[row], 0.0)) / (sc[row] + 1e-30)
+        bad = np.abs(got[row] - np.maximum(wrong[row], 0.0)) / (sc[row] + 1e-30)
+        assert float(ok.max()) <= 1e-5 < float(bad.max()), (row, float(ok.max()), float(bad.max()))
+
+    # ---- every gradient, float64 reverse mode at the engine's own activations
+    g64 = chunked_block_encoder_backward_float64(params, triples, V, L, acts_train, dcodes, mode="train", masks=masks)
+    for k, g in grads.items():
+        if k not in g64 or k.startswith("b") and k != "b_emb":
+            continue
+        emax, el2 = error_against(g64[k], g)
+        assert emax <= 5e-6 and el2 <= 2e-6, (k, emax, el2)

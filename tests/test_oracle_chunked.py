@@ -16,3 +16,33 @@ def test_chunked_float64_decoder_is_the_oracle():
     b = oracle.distmult_loss_and_grads(codes, w_rel, X, Y, 0.01)
     assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
     assert np.abs(a[1] - b[1]).max() <= 1e-6 * np.abs(b[1]).max() and np.abs(a[2] - b[2]).max() <= 1e-6 * np.abs(b[2]).max()
+
+
+def test_chunked_float64_block_encoder_is_the_oracle():
+    """The edge-chunked float64 restatement of the block encoder (tests/helpers.py: what the 272,115-edge GPU test
+    compares with) is oracle.encoder_step on a case both can run -- every norm reading, train and test mode, chunks that
+    cut rows and relations anywhere."""
+    from helpers import (chunked_block_encoder_forward_float64, chunked_block_encoder_backward_float64, make_case,
+                         oracle_float64)
+    params, triples, masks, dcodes = make_case(50, 7, 12, 2, "block", 4, 333, seed=4)
+    c = {"params": params, "triples": triples, "masks": masks, "dcodes": dcodes, "V": 50, "L": 2}
+    for norm in (oracle.NORM_INTENDED, oracle.NORM_TF_AS_EXECUTED, oracle.NORM_NONE):
+        for mode in ("train", "test"):
+            with oracle_float64():
+                p64 = {k: np.asarray(v, dtype=np.float64) for k, v in c["params"].items()}
+                acts, grads = oracle.encoder_step(p64, c["triples"], c["V"], c["L"], "block",
+                                                  c["dcodes"].astype(np.float64), keep_prob=0.8,
+                                                  dropout_masks=c["masks"], norm_mode=norm, mode=mode)
+                # (inside the float64 switch: the 1/deg values are then float64 on both sides; outside it the
+                # restatement takes them in fp32, as the engine and the reference compute them)
+                got, scales = chunked_block_encoder_forward_float64(c["params"], c["triples"], c["V"], c["L"],
+                                                                    mode=mode, masks=c["masks"], norm_mode=norm,
+                                                                    chunk=37, with_scale=True)
+                gg = chunked_block_encoder_backward_float64(c["params"], c["triples"], c["V"], c["L"], acts,
+                                                            c["dcodes"], mode=mode, masks=c["masks"], norm_mode=norm,
+                                                            chunk=41)
+            for a, b, sc in zip(acts, got, scales):
+                assert np.abs(a - b).max() <= 1e-12 * max(np.abs(a).max(), 1.0)
+                assert (np.abs(b) <= sc * (1 + 1e-12) + 1e-300).all()      # the scale bounds the value it belongs to
+            for k, ref in grads.items():
+                assert np.abs(gg[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), k
