@@ -24,7 +24,7 @@ LIB = os.path.join(LIBDIR, "librgcn.so")
 # tools/ and the dense-contraction tests; the product library has none of them
 LIB_DEVTOOLS = os.path.join(LIBDIR, "librgcn_devtools.so")
 ARCH = "gfx950"
-SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "block_spmm.hip", "basis.hip",
+SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "block_msgs.hip", "block_spmm.hip", "block_rows.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "neighborhood.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h"),
            os.path.join(ROOT, "include", "rgcn_devtools.h")]
@@ -36,6 +36,8 @@ DEVTOOLS_SOURCES = ["rgcn_api.hip"]       # the only translation unit the flag c
 # pass prints "not a recognized feature" and ignores it) and the linked code objects are checked.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
+# experiment knobs of throw-away builds (tools/*_ab.sh): extra -D flags, part of the object digest
+FLAGS += [f for f in os.environ.get("RGCN_EXTRA_HIPCC_FLAGS", "").split() if f]
 
 
 def _hipcc():

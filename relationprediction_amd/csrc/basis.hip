@@ -35,12 +35,7 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
   else *p = v[0];
 }
 
-__device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) {
-  if (ds.mode == DROP_NONE) return 1.0f;
-  if (ds.mode == DROP_RNG)
-    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
-  return ds.mask[idx] ? ds.inv_keep : 0.0f;
-}
+__device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) { return drop_factor(ds, idx); }
 
 constexpr int kRowThreads = 1024;
 constexpr int kLongBlocks = 64;    // leading workgroups of a row launch that walk the long-row list

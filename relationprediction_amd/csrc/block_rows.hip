@@ -1,0 +1,673 @@
+// Destination-major, single-pass block-diagonal relational layer (ConcatGcn.compute_messages + combine_messages,
+// code/encoders/message_gcns/gcn_basis_concat.py:35-52,69-83, inside MessageGcn.compute_vertex_embeddings,
+// message_gcn.py:49-79) and its gradient w.r.t. the layer input:
+//     forward   H'[v] = relu?( dropout(S[v]) + sum over the messages into v of  n_m * W[r_m] . H[src_m] )
+//     backward  D'[u] = ( G[u] + sum over the messages out of u of  W[r_m]^T . (n_m * D[dst_m]) ) * relu'(H[u]),
+//               dS'[u] = D'[u] * dropout'
+// straight from the incidence CSR: no [2E, d] message buffer is written and read back (the two-kernel form,
+// block_msgs.hip + k_combine, moves 2 x 60 MB per layer pass that way at FB15k-237 minibatch size, 2 x 1.1 GB at the
+// 272,115-edge training graph).
+//
+// Decomposition (the one DESIGN section 4 argued away on an estimate and round 3's block_spmm.hip did NOT try):
+//   * the row is cut into EIGHT column bands of nb/8 blocks, band x handled by the workgroups with blockIdx % 8 == x,
+//     i.e. by the workgroups the dispatcher places on XCD x: that XCD touches 1/8 of every relation's weights
+//     (0.6 MB at FB15k-237: L2-resident) and 1/8 of every gathered row (250 bytes; the band of the whole [V,d] operand
+//     is 3.6 MB, about one XCD's L2), so the per-message weight re-reads the destination-major form needs are L2 hits
+//     and what crosses the fabric is close to the compulsory traffic (operand + self-loop term in, result out);
+//   * a GROUP of GW lanes (GW = 16 at nb = 100) owns (row, band): lane i holds block b0 + i -- its sd x sd coefficients
+//     come from the weights' own [rel][sd*sd][nb] layout (one dword per coefficient, contiguous across the group), its
+//     sd inputs are 4 sd bytes of a 250-byte contiguous piece of the partner row -- no LDS table, so occupancy is
+//     bounded by registers only;
+//   * short rows (<= kLongRow slots): one group per row, 64 / GW rows per wavefront, the row's slots one after the
+//     other (slot indices fetched lane-parallel, one coalesced load for GW slots, and handed round by ds_bpermute);
+//   * long rows: one WORKGROUP per row, tile by tile of 64 slots -- every group computes the messages of its slots of
+//     the tile into LDS (20 KB), then eight interleaved lanes add them up (lane q: the slots beg + q, beg + q + 8, ...
+//     in increasing order) and the eight partial sums are combined in lane order: the segmented reduction runs over
+//     LDS, the loads it depends on run in parallel; long-row workgroups lead the grid;
+//   * giant rows (full-graph scale, more than kGiantRow slots): kGiantRow-slot pieces, one workgroup each, into the piece
+//     slab; k_combine's finishing pass (elementwise.hip) adds a row's pieces in piece order.
+// Every sum is formed in EXACTLY k_combine's order and every message with k_block_msg_fwd / _bwd's arithmetic, so this
+// kernel and the two-kernel form agree BITWISE (tests/test_gpu_parity.py::test_fused_layer_kernel_equals_the_two_kernel_form, mode 3).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "rgcn_internal.h"
+
+namespace rgcn {
+
+namespace {
+
+template <int N>
+struct __attribute__((packed, aligned(4))) FloatN {
+  float v[N];
+};
+
+struct RowsArgs {
+  const float* X;            // gathered operand [V,d]: H_in (forward), D (backward)
+  const float* W;            // band-tiled weights [2R][8][NT][GW][4] (k_wtile_build)
+  const int32_t* row_ptr;    // [V+1] incidence CSR
+  const int32_t* row_order;  // [V] rows by descending number of slots (long rows last)
+  const int32_t* slot_v;     // per slot: the partner vertex (d_src forward, s_dst backward)
+  const int32_t* slot_rel;   // per slot: directed relation in [0, 2R)
+  const float* slot_norm;    // per slot: neighbour normalisation of that message
+  const int32_t* long_rows;  // rows with more than kLongRow slots (and at most the giant threshold)
+  const int32_t* nlong;
+  const int32_t* piece_row;  // giant-row pieces (null when the cut is off)
+  const int32_t* piece_k;
+  const int32_t* ngiant;
+  float* giant_slab;         // [pieces][d]
+  const float* base;         // [V,d] self-loop term (S forward, G backward); dropout `drop` applies; rows [row_lo,row_hi)
+  const float* gate;         // optional: result *= (gate > 0)
+  float* out;
+  float* out2;               // optional: out * dropout(drop2)
+  DropSpec drop, drop2;
+  int32_t V, d, nb, relu, row_lo, row_hi;
+  int32_t n_long_wg;         // workgroups per band that walk the long-row / piece lists (they lead the grid)
+  int32_t rows_per_wg;       // rows of one short-row workgroup
+  unsigned long long* trace; // diagnostics (RGCN_ROWS_TRACE): per wavefront [start clock, end clock, xcc id | role]
+  int32_t ablate;            // diagnostics (RGCN_ROWS_ABLATE): 1 = long rows skipped, 2 = short rows skipped (WRONG results)
+};
+
+constexpr int kRowsThreads = 256;
+
+// lanes per (row, band) group: the smallest of 8 / 16 / 32 / 64 that holds a band's ceil(nb / 8) blocks
+int rows_group_width(const rgcn_ctx* c) {
+  const int band = (c->nb + 7) / 8;
+  return band <= 8 ? 8 : (band <= 16 ? 16 : (band <= 32 ? 32 : 64));
+}
+
+// One message of lane (group, block b): the sd inputs of the partner row and the relation's sd x sd block.
+template <int SD>
+struct SlotRegs {
+  FloatN<SD> x;
+  float w[SD * SD];
+  float nr;
+};
+
+constexpr int nt_of(int sd) { return (sd * sd + 3) / 4; }       // float4s per (relation, block)
+
+// Band-tiled weights: Wt[rel][band x][t][lane li][c] = W[rel][4 t + c][b0(x) + li]  (zero where 4 t + c >= sd*sd or
+// li is beyond the band).  The GW lanes of a group read their t-th float4 from ONE aligned run of 16 GW bytes: every
+// 128-byte line the vector cache fetches is used whole (the weights' own [rel][sd*sd][nb] layout gives a group 52
+// useful bytes per line touched, and the kernel ran at the vector cache's line rate: 72 us for the short rows).
+__global__ void k_wtile_build(const float* __restrict__ W, float* __restrict__ Wt, int R2, int nb, int sd2, int nt, int gw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one float4 of Wt
+  if (i >= (int64_t)R2 * 8 * nt * gw) return;
+  const int li = (int)(i % gw);
+  const int t = (int)((i / gw) % nt);
+  const int x = (int)((i / ((int64_t)gw * nt)) % 8);
+  const int rel = (int)(i / ((int64_t)gw * nt * 8));
+  const int b0 = (x * nb) >> 3, b1 = ((x + 1) * nb) >> 3;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b0 + li < b1) {
+    const float* wp = W + ((size_t)rel * sd2 + 4 * t) * nb + b0 + li;
+    if (4 * t + 0 < sd2) o.x = wp[0];
+    if (4 * t + 1 < sd2) o.y = wp[(size_t)nb];
+    if (4 * t + 2 < sd2) o.z = wp[2 * (size_t)nb];
+    if (4 * t + 3 < sd2) o.w = wp[3 * (size_t)nb];
+  }
+  reinterpret_cast<float4*>(Wt)[i] = o;
+}
+
+// wq: this lane's float4 column of the band's tile, Wt + ((x * NT) * GW + li) * 4; a relation is 8 NT GW float4s on
+template <int SD, int GW>
+__device__ __forceinline__ void slot_load(const RowsArgs& a, const float4* __restrict__ wq, int pv, int rl, float nr,
+                                          int col, SlotRegs<SD>& r) {
+  constexpr int NT = nt_of(SD);
+  r.x = *reinterpret_cast<const FloatN<SD>*>(a.X + (size_t)pv * a.d + col);
+  const float4* wp = wq + (size_t)rl * (8 * NT * GW);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 q = wp[t * GW];
+    r.w[4 * t] = q.x;
+    if (4 * t + 1 < SD * SD) r.w[4 * t + 1] = q.y;
+    if (4 * t + 2 < SD * SD) r.w[4 * t + 2] = q.z;
+    if (4 * t + 3 < SD * SD) r.w[4 * t + 3] = q.w;
+  }
+  r.nr = nr;
+}
+
+// the message's contribution to this lane's sd outputs: the arithmetic of k_block_msg_fwd / k_block_msg_bwd
+template <int SD, bool BWD>
+__device__ __forceinline__ void slot_value(const SlotRegs<SD>& r, float (&y)[SD]) {
+#pragma clang fp contract(off)
+  if constexpr (!BWD) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) {
+      float t = 0.0f;
+#pragma unroll
+      for (int q = 0; q < SD; ++q) t = fmaf(r.w[i * SD + q], r.x.v[q], t);   // out_i = sum_j T[i][j] x_j
+      y[i] = t * r.nr;
+    }
+  } else {
+    float gr[SD];
+#pragma unroll
+    for (int q = 0; q < SD; ++q) gr[q] = r.x.v[q] * r.nr;
+#pragma unroll
+    for (int q = 0; q < SD; ++q) {
+      float z = 0.0f;
+#pragma unroll
+      for (int i = 0; i < SD; ++i) z = fmaf(r.w[i * SD + q], gr[i], z);      // (T^T (n g))_j
+      y[q] = z;
+    }
+  }
+}
+
+// Row state of lane (group, block b): the self-loop term and the gate of its sd outputs, fetched when the row is taken up
+// (the loads then fly under the row's messages).
+template <int SD>
+struct RowRegs {
+  FloatN<SD> base, gate;
+  bool has_base;
+};
+
+template <int SD>
+__device__ __forceinline__ void row_open(const RowsArgs& a, int v, size_t off, RowRegs<SD>& r) {
+  r.has_base = a.base != nullptr && v >= a.row_lo && v < a.row_hi;
+  if (a.base != nullptr) r.base = *reinterpret_cast<const FloatN<SD>*>(a.base + off);      // (uniform test)
+  if (a.gate != nullptr) r.gate = *reinterpret_cast<const FloatN<SD>*>(a.gate + off);
+}
+
+// the lane's sd dropout factors: ONE (uniform) dispatch on the spec's mode for all of them
+template <int SD>
+__device__ __forceinline__ void drop_factors(const DropSpec& ds, const DropKey& k, size_t off, float (&f)[SD]) {
+  if (ds.mode == DROP_RNG) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) f[i] = drop_bits24(k, off + i) < ds.thresh ? ds.inv_keep : 0.0f;
+  } else if (ds.mode == DROP_MASK) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) f[i] = ds.mask[off + i] ? ds.inv_keep : 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) f[i] = 1.0f;
+  }
+}
+
+// tot = dropout(base)  (k_combine's prologue: scale, no fused multiply-add with what follows)
+template <int SD>
+__device__ __forceinline__ void row_prologue(const RowsArgs& a, const DropKey& k1, const RowRegs<SD>& r, size_t off,
+                                             float (&tot)[SD]) {
+#pragma clang fp contract(off)
+  float f[SD];
+  drop_factors<SD>(a.drop, k1, off, f);
+#pragma unroll
+  for (int i = 0; i < SD; ++i) {
+    float t = r.base.v[i];
+    t *= f[i];
+    tot[i] = r.has_base ? t : 0.0f;
+  }
+}
+
+// relu' gate, relu, store, dropout-scaled second copy (k_combine's epilogue)
+template <int SD>
+__device__ __forceinline__ void row_epilogue(const RowsArgs& a, const DropKey& k2, const RowRegs<SD>& r, size_t off,
+                                             const float (&tot)[SD], bool store) {
+#pragma clang fp contract(off)
+  FloatN<SD> o, o2;
+  float f[SD];
+  if (a.out2 != nullptr) drop_factors<SD>(a.drop2, k2, off, f);
+#pragma unroll
+  for (int i = 0; i < SD; ++i) {
+    float val = tot[i];
+    if (a.gate != nullptr) val = r.gate.v[i] > 0.0f ? val : 0.0f;
+    if (a.relu) val = fmaxf(val, 0.0f);
+    o.v[i] = val;
+    o2.v[i] = a.out2 != nullptr ? val * f[i] : 0.0f;
+  }
+  if (store) {
+    *reinterpret_cast<FloatN<SD>*>(a.out + off) = o;
+    if (a.out2 != nullptr) *reinterpret_cast<FloatN<SD>*>(a.out2 + off) = o2;
+  }
+}
+
+// Lanes of slot tiles: phase 1 of a long row computes the messages of TS consecutive slots in parallel (one group per
+// slot and turn) into LDS, phase 2 adds them up in k_combine's long-row order.  TS x GW x SD floats <= 20 KB, so that
+// the LDS never bounds the occupancy the registers allow.
+template <int SD, int GW>
+struct LongTile {
+  static constexpr int TS = GW * SD <= 80 ? 64 : (GW * SD <= 160 ? 32 : (GW * SD <= 320 ? 16 : 8));
+  static constexpr int NGW = (kRowsThreads / 64) * (64 / GW);      // groups of a workgroup
+  static constexpr int SPG = TS / NGW;                              // slots per group and tile
+  static constexpr int PT = 8 * GW < kRowsThreads ? 8 * GW : kRowsThreads;   // phase-2 threads
+  static constexpr int NQ = 8 * GW / PT;                            // interleaved lanes per phase-2 thread
+  static_assert(TS % 8 == 0 && SPG >= 2 && SPG % 2 == 0, "tile geometry");
+};
+
+// Sum of the slots [beg, end) by the whole workgroup in k_combine's long-row order: eight interleaved lanes (lane q
+// adds the slots beg + q, beg + q + 8, ... in increasing order), combined ((0 + 1) + 2) ... + 7.  The MESSAGES are
+// computed tile by tile with every group of the workgroup busy (a hub row is a chain of hundreds of dependent adds but
+// its messages are independent: one wavefront walking the chain with its loads in line took ~80 us for a 431-slot hub);
+// the chain itself then runs over LDS.  The result is valid in the threads tid < GW (= group 0 of wave 0).
+template <int SD, bool BWD, int GW>
+__device__ __forceinline__ void wg_long_sum(const RowsArgs& a, int beg, int end, float* __restrict__ ybuf,
+                                            const float4* __restrict__ wq, int col, float (&sum)[SD]) {
+#pragma clang fp contract(off)
+  using T = LongTile<SD, GW>;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane % GW;
+  const int G = (tid >> 6) * (64 / GW) + lane / GW;                 // group of the workgroup
+  float part[T::NQ][SD];
+#pragma unroll
+  for (int jj = 0; jj < T::NQ; ++jj)
+#pragma unroll
+    for (int i = 0; i < SD; ++i) part[jj][i] = 0.0f;
+  for (int c0 = beg; c0 < end; c0 += T::TS) {
+    // ---- phase 1: the tile's messages.  Every wavefront fetches the tile's indices itself (one coalesced load per
+    // array) and hands them round by ds_bpermute
+    const int sl = c0 + lane;
+    const bool ok = lane < T::TS && sl < end;
+    const int my_pv = ok ? a.slot_v[sl] : 0;
+    const int my_rl = ok ? a.slot_rel[sl] : 0;
+    const float my_nr = ok ? a.slot_norm[sl] : 0.0f;
+#if ROWS_SIF == 2
+#pragma unroll
+    for (int u = 0; u < T::SPG; u += 2) {
+      const int s0 = G + T::NGW * u, s1 = G + T::NGW * (u + 1);
+      const int pv0 = __shfl(my_pv, s0, 64), rl0 = __shfl(my_rl, s0, 64);
+      const int pv1 = __shfl(my_pv, s1, 64), rl1 = __shfl(my_rl, s1, 64);
+      const float nr0 = __shfl(my_nr, s0, 64), nr1 = __shfl(my_nr, s1, 64);
+      if (c0 + s0 < end) {                 // (group-uniform; s1 > s0: a live s1 implies a live s0)
+        SlotRegs<SD> r0, r1;
+        slot_load<SD, GW>(a, wq, pv0, rl0, nr0, col, r0);
+        slot_load<SD, GW>(a, wq, pv1, rl1, nr1, col, r1);    // a dead s1 reads slot data of vertex 0: valid addresses
+        float y0[SD], y1[SD];
+        slot_value<SD, BWD>(r0, y0);
+        slot_value<SD, BWD>(r1, y1);
+#pragma unroll
+        for (int i = 0; i < SD; ++i) {
+          ybuf[(s0 * GW + li) * SD + i] = y0[i];
+          ybuf[(s1 * GW + li) * SD + i] = y1[i];
+        }
+      }
+    }
+#else
+#pragma unroll
+    for (int u = 0; u < T::SPG; ++u) {
+      const int s0 = G + T::NGW * u;
+      const int pv0 = __shfl(my_pv, s0, 64), rl0 = __shfl(my_rl, s0, 64);
+      const float nr0 = __shfl(my_nr, s0, 64);
+      if (c0 + s0 < end) {                 // (group-uniform)
+        SlotRegs<SD> r0;
+        slot_load<SD, GW>(a, wq, pv0, rl0, nr0, col, r0);
+        float y0[SD];
+        slot_value<SD, BWD>(r0, y0);
+#pragma unroll
+        for (int i = 0; i < SD; ++i) ybuf[(s0 * GW + li) * SD + i] = y0[i];
+      }
+    }
+#endif
+    __syncthreads();
+    // ---- phase 2: thread (q, li) adds lane q's slots of the tile, in increasing order
+    if (tid < T::PT) {
+#pragma unroll
+      for (int jj = 0; jj < T::NQ; ++jj) {
+        const int q = tid / GW + jj * (T::PT / GW), pl = tid % GW;
+        const int nlive = min(T::TS, end - c0);
+#pragma unroll
+        for (int t = 0; t < T::TS / 8; ++t) {
+          const int s = q + 8 * t;
+          if (s < nlive) {
+#pragma unroll
+            for (int i = 0; i < SD; ++i) part[jj][i] = part[jj][i] + ybuf[(s * GW + pl) * SD + i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the eight lanes in lane order
+  if (tid < T::PT) {
+#pragma unroll
+    for (int jj = 0; jj < T::NQ; ++jj) {
+      const int q = tid / GW + jj * (T::PT / GW), pl = tid % GW;
+#pragma unroll
+      for (int i = 0; i < SD; ++i) ybuf[(q * GW + pl) * SD + i] = part[jj][i];
+    }
+  }
+  __syncthreads();
+  if (tid < GW) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) {
+      float t = ybuf[(0 * GW + tid) * SD + i];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t = t + ybuf[(q * GW + tid) * SD + i];
+      sum[i] = t;
+    }
+  }
+  __syncthreads();
+}
+
+#ifndef ROWS_MW
+#define ROWS_MW 1
+#endif
+#ifndef ROWS_SIF
+#define ROWS_SIF 2
+#endif
+template <int SD, bool BWD, int GW>
+__global__ void __launch_bounds__(kRowsThreads, ROWS_MW) k_block_rows(RowsArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NG = 64 / GW;
+  __shared__ float ybuf[LongTile<SD, GW>::TS * GW * SD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GW, li = lane % GW;
+  // band of this workgroup's XCD
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int b0 = (x * a.nb) >> 3, b1 = ((x + 1) * a.nb) >> 3;
+  const int nbx = b1 - b0;
+  if (nbx <= 0) return;
+  const bool lane_ok = li < nbx;
+  const int b = b0 + (lane_ok ? li : nbx - 1);       // idle lanes shadow the band's last block (loads only)
+  const int col = b * SD;
+  const float4* wq = reinterpret_cast<const float4*>(a.W) + ((size_t)x * nt_of(SD)) * GW + li;
+  const DropKey key1 = drop_key(a.drop), key2 = drop_key(a.drop2);
+  struct Trace {
+    unsigned long long* p; unsigned long long t0; int role;
+    unsigned long long init = 0, wait = 0, mark = 0;
+    __device__ void sync_mark() {      // diagnostic: drain every counter, then stamp
+      if (p) { __builtin_amdgcn_s_waitcnt(0); mark = (unsigned long long)wall_clock64(); }
+    }
+    __device__ void add_wait() {
+      if (p) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t = (unsigned long long)wall_clock64(); wait += t - mark; mark = t; }
+    }
+    __device__ ~Trace() {
+      if (p && (threadIdx.x & 63) == 0) {
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p[0] = t0; p[1] = (unsigned long long)wall_clock64(); p[2] = ((unsigned long long)(xcc & 15) << 8) | (unsigned)role;
+        p[3] = init; p[4] = wait; p[5] = 0;
+      }
+    }
+  } tr{a.trace ? a.trace + ((size_t)blockIdx.x * (kRowsThreads / 64) + wave) * 6 : nullptr, (unsigned long long)wall_clock64(),
+       j < a.n_long_wg ? 1 : 0};
+
+  if (j < a.n_long_wg) {
+    // ---- long rows and giant-row pieces: one workgroup each
+    if (a.ablate == 1) return;
+    const bool writer = threadIdx.x < GW && lane_ok;
+    const int n = *a.nlong;
+    for (int idx = j; idx < n; idx += a.n_long_wg) {
+      const int v = a.long_rows[idx];
+      const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      const size_t off = (size_t)v * a.d + col;
+      float tot[SD], sum[SD];
+      RowRegs<SD> rr;
+      if (writer) row_open<SD>(a, v, off, rr);
+      wg_long_sum<SD, BWD, GW>(a, beg, end, ybuf, wq, col, sum);
+      if (writer) {
+        row_prologue<SD>(a, key1, rr, off, tot);
+#pragma unroll
+        for (int i = 0; i < SD; ++i) tot[i] = tot[i] + sum[i];
+        row_epilogue<SD>(a, key2, rr, off, tot, true);
+      }
+    }
+    if (a.ngiant != nullptr) {
+      const int np = a.ngiant[1];
+      for (int p = j; p < np; p += a.n_long_wg) {
+        const int v = a.piece_row[p];
+        const int beg = a.row_ptr[v] + a.piece_k[p] * kGiantRow;
+        const int end = min(a.row_ptr[v + 1], beg + kGiantRow);
+        float sum[SD];
+        wg_long_sum<SD, BWD, GW>(a, beg, end, ybuf, wq, col, sum);
+        if (writer) {
+          FloatN<SD> o;
+#pragma unroll
+          for (int i = 0; i < SD; ++i) o.v[i] = sum[i];
+          *reinterpret_cast<FloatN<SD>*>(a.giant_slab + (size_t)p * a.d + col) = o;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- short rows: one group per row, NG rows per wavefront and turn.  Rows come in the order of graph_prep's
+  // row_order (descending number of slots): the NG rows of a turn have the same length, so the wavefront does not
+  // idle on its longest row (in vertex order 59 % of the lane-slots were idle), and the heavy workgroups start first.
+  // A wavefront owns RW consecutive positions: row ids and row pointers of all its turns come with two coalesced loads,
+  // the slot indices of turn t + 1 are fetched under the messages of turn t.
+  if (a.ablate == 2) return;
+  // Turn t of wavefront W (of NW) takes the NG consecutive positions (t NW + W) NG ..: the rows of a turn are
+  // neighbours in the sorted order (equal lengths), the turns of a wavefront are dealt from the whole order like
+  // cards -- every wavefront gets its share of heavy and of light rows (contiguous chunks of the sorted order left the
+  // first workgroups with all the 32-slot rows: 75 us at 64 rows per workgroup against 47 at 32).
+  const int RW = a.rows_per_wg / (kRowsThreads / 64);                 // rows of a wavefront, <= 64
+  const int nturn = RW / NG;
+  const int W = (j - a.n_long_wg) * (kRowsThreads / 64) + wave;
+  const int NW = (int)(gridDim.x >> 3) - a.n_long_wg;
+  const int NWtot = NW * (kRowsThreads / 64);
+  int my_v = -1, my_beg = 0, my_n = 0;
+  {
+    const int t = lane / NG, gg = lane % NG;
+    const int p = (t * NWtot + W) * NG + gg;
+    if (t < nturn && p < a.V) {
+      my_v = a.row_order[p];
+      my_beg = a.row_ptr[my_v];
+      my_n = a.row_ptr[my_v + 1] - my_beg;
+      if (my_n > kLongRow) { my_v = -1; my_n = 0; }      // a long-row workgroup (or the giant-row pass) owns this row
+    }
+  }
+  if (tr.p) { __builtin_amdgcn_s_waitcnt(0); tr.init = (unsigned long long)wall_clock64() - tr.t0; }
+  auto fetch_idx = [&](int beg, int n, int c0, int& pv, int& rl, float& nr) {
+    const bool ok = c0 + li < n;                        // this group's next GW slot indices, one coalesced load per array
+    pv = ok ? a.slot_v[beg + c0 + li] : 0;
+    rl = ok ? a.slot_rel[beg + c0 + li] : 0;
+    nr = ok ? a.slot_norm[beg + c0 + li] : 0.0f;
+  };
+  int v = __shfl(my_v, g, 64), beg = __shfl(my_beg, g, 64), n = __shfl(my_n, g, 64);
+  int my_pv, my_rl;
+  float my_nr;
+  fetch_idx(beg, n, 0, my_pv, my_rl, my_nr);
+  for (int turn = 0; turn < nturn; ++turn) {
+    const int src = min((turn + 1) * NG + g, 63);
+    const bool more = turn + 1 < nturn;
+    const int v2 = more ? __shfl(my_v, src, 64) : -1;
+    const int beg2 = more ? __shfl(my_beg, src, 64) : 0, n2 = more ? __shfl(my_n, src, 64) : 0;
+    int pv2, rl2;
+    float nr2;
+    fetch_idx(beg2, n2, 0, pv2, rl2, nr2);
+    // rows come by descending length: group 0 holds the turn's longest row, so the loop bounds are SCALAR (lane 0's
+    // row) and the other groups are predicated -- no exec-mask bookkeeping in the slot loop; a group whose row is
+    // shorter (a class boundary of the order, rare) re-reads its last slot and discards the value
+    const int n_u = __builtin_amdgcn_readfirstlane(n);
+    if (__builtin_amdgcn_readfirstlane(v) >= 0) {
+      const bool live_row = v >= 0;
+      const int ve = live_row ? v : 0;
+      const size_t off = (size_t)ve * a.d + col;
+      RowRegs<SD> rr;
+      row_open<SD>(a, ve, off, rr);
+      float tot[SD];
+      if (n_u == 0) {
+        row_prologue<SD>(a, key1, rr, off, tot);
+      } else {
+#if ROWS_SIF == 2
+        // the row's slots, two at a time; the self-loop term (requested first) is scaled under the first pair's loads
+        SlotRegs<SD> r0, r1;
+        tr.sync_mark();
+        {
+          const int s0 = g * GW, s1 = g * GW + (n_u > 1 ? 1 : 0);
+          slot_load<SD, GW>(a, wq, __shfl(my_pv, s0, 64), __shfl(my_rl, s0, 64), __shfl(my_nr, s0, 64), col, r0);
+          slot_load<SD, GW>(a, wq, __shfl(my_pv, s1, 64), __shfl(my_rl, s1, 64), __shfl(my_nr, s1, 64), col, r1);
+        }
+        tr.add_wait();
+        row_prologue<SD>(a, key1, rr, off, tot);
+        for (int c0 = 0; c0 < n_u; c0 += GW) {
+          if (c0 > 0) fetch_idx(beg, n, c0, my_pv, my_rl, my_nr);
+          const int m_u = min(GW, n_u - c0);
+          for (int k = 0; k < m_u; k += 2) {
+            if (c0 + k > 0) {
+              tr.sync_mark();
+              const int s0 = g * GW + k, s1 = g * GW + min(k + 1, m_u - 1);
+              slot_load<SD, GW>(a, wq, __shfl(my_pv, s0, 64), __shfl(my_rl, s0, 64), __shfl(my_nr, s0, 64), col, r0);
+              slot_load<SD, GW>(a, wq, __shfl(my_pv, s1, 64), __shfl(my_rl, s1, 64), __shfl(my_nr, s1, 64), col, r1);
+              tr.add_wait();
+            }
+            float y0[SD], y1[SD];
+            slot_value<SD, BWD>(r0, y0);
+            slot_value<SD, BWD>(r1, y1);
+            const bool live0 = c0 + k < n, live1 = c0 + k + 1 < n;
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+              const float t0 = tot[i] + y0[i];
+              tot[i] = live0 ? t0 : tot[i];
+              const float t1 = tot[i] + y1[i];
+              tot[i] = live1 ? t1 : tot[i];
+            }
+          }
+        }
+#else
+        // the row's slots one at a time (fewer registers, more wavefronts per SIMD)
+        SlotRegs<SD> r0;
+        tr.sync_mark();
+        slot_load<SD, GW>(a, wq, __shfl(my_pv, g * GW, 64), __shfl(my_rl, g * GW, 64), __shfl(my_nr, g * GW, 64), col, r0);
+        tr.add_wait();
+        row_prologue<SD>(a, key1, rr, off, tot);
+        for (int c0 = 0; c0 < n_u; c0 += GW) {
+          if (c0 > 0) fetch_idx(beg, n, c0, my_pv, my_rl, my_nr);
+          const int m_u = min(GW, n_u - c0);
+          for (int k = 0; k < m_u; ++k) {
+            if (c0 + k > 0) {
+              tr.sync_mark();
+              const int s0 = g * GW + k;
+              slot_load<SD, GW>(a, wq, __shfl(my_pv, s0, 64), __shfl(my_rl, s0, 64), __shfl(my_nr, s0, 64), col, r0);
+              tr.add_wait();
+            }
+            float y0[SD];
+            slot_value<SD, BWD>(r0, y0);
+            const bool live0 = c0 + k < n;
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+              const float t0 = tot[i] + y0[i];
+              tot[i] = live0 ? t0 : tot[i];
+            }
+          }
+        }
+#endif
+      }
+      row_epilogue<SD>(a, key2, rr, off, tot, live_row && lane_ok);
+    }
+    v = v2; beg = beg2; n = n2;
+    my_pv = pv2; my_rl = rl2; my_nr = nr2;
+  }
+}
+
+template <int SD, int GW>
+hipError_t launch_rows(rgcn_ctx* c, const RowsArgs& a, bool backward, int grid) {
+  if (backward) hipLaunchKernelGGL((k_block_rows<SD, true, GW>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_block_rows<SD, false, GW>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
+  return hipGetLastError();
+}
+
+template <int SD>
+hipError_t launch_rows_gw(rgcn_ctx* c, const RowsArgs& a, bool backward, int grid, int gw) {
+  switch (gw) {
+    case 8: return launch_rows<SD, 8>(c, a, backward, grid);
+    case 16: return launch_rows<SD, 16>(c, a, backward, grid);
+    case 32: return launch_rows<SD, 32>(c, a, backward, grid);
+    default: return launch_rows<SD, 64>(c, a, backward, grid);
+  }
+}
+
+}  // namespace
+
+
+bool block_rows_available(const rgcn_ctx* c) {
+  return c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->nb <= 512 && c->g.d_src != nullptr && c->g.row_order != nullptr;
+}
+
+// band-tiled copy of a layer's relation weights, rebuilt when the weights changed (set_param, Adam) -- and inside every
+// captured step, whose replays follow weights the host does not see
+static rgcn_status block_rows_refresh_weights(rgcn_ctx* c, int layer) {
+  LayerBufs& lb = c->layers[layer];
+  const int gw = rows_group_width(c), nt = nt_of(c->sd);
+  const int64_t n4 = (int64_t)2 * c->R * 8 * nt * gw;
+  if (!lb.wtile) RGCN_HIP(c, hipMalloc((void**)&lb.wtile, sizeof(float) * 4 * (size_t)n4));
+  if (!c->capturing && lb.wtile_version == c->weights_version) return RGCN_OK;
+  ProfScope ps(c, "block_wtile_build", 4.0 * (2.0 * c->R * c->sd * c->sd * c->nb) + 16.0 * n4, 0);
+  hipLaunchKernelGGL(k_wtile_build, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, lb.wrel, lb.wtile,
+                     2 * c->R, c->nb, c->sd * c->sd, nt, gw);
+  RGCN_HIP(c, hipGetLastError());
+  lb.wtile_version = c->capturing ? ~0ull : c->weights_version;
+  return RGCN_OK;
+}
+
+rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca) {
+  RGCN_TRY(block_rows_refresh_weights(c, layer));
+  RowsArgs a;
+  a.X = X;
+  a.W = c->layers[layer].wtile;
+  a.row_ptr = c->g.row_ptr;
+  a.row_order = c->g.row_order;
+  a.slot_v = backward ? c->g.s_dst : c->g.d_src;
+  a.slot_rel = backward ? c->g.s_rel : c->g.d_rel;
+  a.slot_norm = backward ? c->g.s_norm : c->g.d_norm;
+  a.long_rows = c->g.long_rows;
+  a.nlong = c->g.nlong;
+  const bool giant = c->g.giant_on;
+  if (giant && !c->giant_slab)
+    RGCN_HIP(c, hipMalloc((void**)&c->giant_slab, sizeof(float) * (size_t)c->g.piece_cap * c->d));
+  a.piece_row = giant ? c->g.piece_row : nullptr;
+  a.piece_k = giant ? c->g.piece_k : nullptr;
+  a.ngiant = giant ? c->g.ngiant : nullptr;
+  a.giant_slab = giant ? c->giant_slab : nullptr;
+  a.base = ca.base; a.gate = ca.gate; a.out = ca.out; a.out2 = ca.out2; a.drop = ca.drop; a.drop2 = ca.drop2;
+  a.V = c->V; a.d = c->d; a.nb = c->nb; a.relu = ca.relu; a.row_lo = ca.row_lo; a.row_hi = ca.row_hi;
+  static const int rpw_env = getenv("RGCN_ROWS_PER_WG") ? atoi(getenv("RGCN_ROWS_PER_WG")) : 0;
+  static const int lwg_env = getenv("RGCN_ROWS_LONG_WG") ? atoi(getenv("RGCN_ROWS_LONG_WG")) : 0;
+  // rows of a short-row workgroup: a multiple of 4 NG (whole turns for its four wavefronts), at most 256
+  {
+    const int quantum = 4 * (64 / rows_group_width(c));
+    int rpw = rpw_env > 0 ? rpw_env : 64;
+    rpw = std::max(quantum, std::min(256, rpw / quantum * quantum));
+    a.rows_per_wg = rpw;
+  }
+  static const int ablate_env = getenv("RGCN_ROWS_ABLATE") ? atoi(getenv("RGCN_ROWS_ABLATE")) : 0;
+  a.ablate = ablate_env;
+  // one workgroup per long row and turn: about one per 256 slots of the graph, 32 .. 1024 workgroups per band
+  int64_t want = lwg_env > 0 ? lwg_env : (2 * c->g.E) / 256;
+  a.n_long_wg = c->g.E > 0 ? (int)std::max<int64_t>(32, std::min<int64_t>(1024, want)) : 0;
+  const int n_row_wg = (c->V + a.rows_per_wg - 1) / a.rows_per_wg;
+  const int grid = 8 * (a.n_long_wg + n_row_wg);
+  const double M = 2.0 * c->g.E, P = 4.0 * c->V * c->d;
+  const double Wb = 8.0 * c->R * c->nb * c->sd * c->sd;
+  const double streams = (ca.base ? 1.0 : 0.0) + (ca.gate ? 1.0 : 0.0) + 1.0 + (ca.out2 ? 1.0 : 0.0);
+  const double rows = M < c->V ? M : (double)c->V;
+  // design: every slot gathers one operand row and one relation's weights (through L2), the slot arrays once per band;
+  // compulsory: the distinct gathered rows once, the slot arrays and the weights once, the row streams once
+  ProfScope ps(c, tag, 4.0 * c->d * M + streams * P + 12.0 * M * 8.0 + 4.0 * c->sd * c->sd * c->nb * M + 4.0 * c->V,
+               M * 2.0 * c->d * c->sd, 4.0 * c->d * rows + streams * P + 12.0 * M + Wb + 4.0 * c->V);
+  hipError_t e = hipSuccess;
+  const int gw = rows_group_width(c);
+  static const char* trace_env = getenv("RGCN_ROWS_TRACE");
+  a.trace = nullptr;
+  const size_t trace_n = (size_t)grid * (kRowsThreads / 64) * 6;
+  if (trace_env) {
+    RGCN_HIP(c, hipMalloc((void**)&a.trace, trace_n * 8));
+    RGCN_HIP(c, hipMemsetAsync(a.trace, 0, trace_n * 8, c->stream));
+  }
+#define RGCN_ROWS_CASE(SDV) \
+  case SDV: e = launch_rows_gw<SDV>(c, a, backward, grid, gw); break;
+  switch (c->sd) {
+    RGCN_ROWS_CASE(1) RGCN_ROWS_CASE(2) RGCN_ROWS_CASE(3) RGCN_ROWS_CASE(4) RGCN_ROWS_CASE(5) RGCN_ROWS_CASE(8)
+    default: RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "block size d/nb must be one of 1,2,3,4,5,8");
+  }
+#undef RGCN_ROWS_CASE
+  RGCN_HIP(c, e);
+  if (trace_env) {
+    std::vector<unsigned long long> h(trace_n);
+    RGCN_HIP(c, hipStreamSynchronize(c->stream));
+    RGCN_HIP(c, hipMemcpy(h.data(), a.trace, trace_n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(a.trace);
+    if (FILE* f = fopen(trace_env, "ab")) {
+      const long long hdr[4] = {(long long)trace_n, grid, a.n_long_wg, backward ? 1 : 0};
+      fwrite(hdr, 8, 4, f);
+      fwrite(h.data(), 8, trace_n, f);
+      fclose(f);
+    }
+  }
+  if (giant) {
+    CombineArgs f = ca;
+    f.msg = nullptr; f.add = nullptr;
+    RGCN_TRY(combine_giant_finish(c, f));
+  }
+  return RGCN_OK;
+}
+
+}  // namespace rgcn

@@ -297,12 +297,13 @@ __global__ void k_scale_dropout(const float* __restrict__ in, float* __restrict_
                                 DropSpec ds) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const DropKey key = drop_key(ds);
   for (; i < nvec; i += stride) {
     const size_t off = (size_t)i * VEC;
     float v[VEC];
     vload<VEC>(in + off, v);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) v[k] *= drop_scale(ds, off + k);
+    for (int k = 0; k < VEC; ++k) v[k] *= drop_factor(ds, key, off + k);
     vstore<VEC>(out + off, v);
   }
 }
@@ -319,7 +320,8 @@ __global__ void k_relu_copy(const float* __restrict__ in, float* __restrict__ ou
 __global__ void k_materialize_mask(uint8_t* out, int64_t n, DropSpec ds) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = drop_scale(ds, (size_t)i) != 0.0f ? 1 : 0;
+  const DropKey key = drop_key(ds);
+  for (; i < n; i += stride) out[i] = drop_factor(ds, key, (size_t)i) != 0.0f ? 1 : 0;
 }
 
 // column sums of a [rows, cols] matrix, deterministic two-stage reduction.
@@ -464,6 +466,20 @@ rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a_in, doubl
     if (vec4) hipLaunchKernelGGL((k_combine_giant_finish<4>), dim3(64), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_combine_giant_finish<1>), dim3(64), dim3(256), 0, c->stream, a);
   }
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status combine_giant_finish(rgcn_ctx* c, const CombineArgs& a_in) {
+  if (!c->g.giant_on) return RGCN_OK;
+  CombineArgs a = a_in;
+  if (!c->giant_slab) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: giant-row pieces were never written");
+  a.giant_rows = c->g.giant_rows; a.giant_first = c->g.giant_first; a.giant_cnt = c->g.giant_cnt;
+  a.piece_row = c->g.piece_row; a.piece_k = c->g.piece_k; a.ngiant = c->g.ngiant; a.giant_slab = c->giant_slab;
+  const bool vec4 = (a.d % 4 == 0) && aligned16(a.out) && aligned16(a.base) && aligned16(a.add) && aligned16(a.gate) &&
+                    aligned16(a.out2);
+  if (vec4) hipLaunchKernelGGL((k_combine_giant_finish<4>), dim3(64), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_combine_giant_finish<1>), dim3(64), dim3(256), 0, c->stream, a);
   RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }

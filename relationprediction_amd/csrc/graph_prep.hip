@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
                                                int32_t* long_rows, int32_t* nlong, int cap, int giant_threshold,
                                                int32_t* giant_rows, int32_t* giant_first, int32_t* giant_cnt,
                                                int32_t* piece_row, int32_t* piece_k, int32_t* ngiant, int giant_cap,
-                                               int piece_cap, int32_t* rel_ptr, int32_t* chunk_ptr) {
+                                               int piece_cap, int32_t* rel_ptr, int32_t* chunk_ptr,
+                                               uint32_t* row_key) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   row_ptr[v] = beg;
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1));
+  if (row_key != nullptr) row_key[v] = end - beg > kLongRow ? (uint32_t)(kLongRow + 1) : (uint32_t)(kLongRow - (end - beg));
   if (degrees_from_rows) {
     // all relations are local: row v holds every incidence of v, the stable sort put the incidences
     // with index < E (edges arriving at v) first -> in-degree = position of the first index >= E
@@ -470,13 +472,19 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   RGCN_TRY(dalloc(c, &g.m_dslot, M));
   RGCN_TRY(dalloc(c, &g.m_sslot, M));
   RGCN_TRY(dalloc(c, &g.m_norm, M));
-  if (c->kind == RGCN_KIND_BASIS || block_spmm_available(c)) {      // slot-ordered message lists (row-major gathers)
+  if (c->kind == RGCN_KIND_BASIS || c->world == 1) {      // slot-ordered message lists (row-major gathers)
     RGCN_TRY(dalloc(c, &g.d_src, M));
     RGCN_TRY(dalloc(c, &g.d_rel, M));
     RGCN_TRY(dalloc(c, &g.d_norm, M));
     RGCN_TRY(dalloc(c, &g.s_dst, M));
     RGCN_TRY(dalloc(c, &g.s_rel, M));
     RGCN_TRY(dalloc(c, &g.s_norm, M));
+  }
+  if (c->kind == RGCN_KIND_BLOCK && c->world == 1) {
+    RGCN_TRY(dalloc(c, &g.row_key, V));
+    RGCN_TRY(dalloc(c, &g.row_key_s, V));
+    RGCN_TRY(dalloc(c, &g.row_order, V));
+    RGCN_TRY(dalloc(c, &g.row_tab, sort_table_elems(V)));
   }
   if (share) {
     g.owner = share->owner;
@@ -506,7 +514,8 @@ static void graph_free_one(GraphBufs& g, bool owns_shared) {
   void* ptrs[] = {g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row, g.piece_k, g.long_rows, g.triples, g.counters, g.row_ptr, g.rel_ptr, g.chunk_ptr, g.cum_in, g.cum_out,
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel,
-                  g.s_norm, g.owner, g.errflag, g.keyv_t, g.keyr_t, g.tablev, g.tabler};
+                  g.s_norm, g.owner, g.errflag, g.keyv_t, g.keyr_t, g.tablev, g.tabler, g.row_key, g.row_key_s, g.row_order,
+                  g.row_tab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g = GraphBufs();
@@ -555,7 +564,13 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                        g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows,
                        g.nlong, g.long_cap,
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
-                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr);
+                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr, g.row_key);
+  }
+  if (g.row_key != nullptr) {
+    // rows by descending length (stable, one 8-bit pass of the library's radix sort over V keys <= 33)
+    SortSpec sp{g.row_key, g.row_key_s, g.row_order, g.row_key_s, g.row_order, nullptr, g.row_tab, (int64_t)V,
+                (uint32_t)(kLongRow + 1)};
+    RGCN_TRY(sort_pairs(c, "prep_row_order", 1, &sp));
   }
   if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
     ScanJobs jobs;

@@ -257,7 +257,7 @@ static void free_all(rgcn_ctx* c) {
       lb.gwself = nullptr;
       if (c->kind == RGCN_KIND_BASIS) lb.grel = nullptr;
     }
-    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wbm);
+    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wbm); F(lb.wtile);
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
@@ -428,7 +428,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_TRY(dmalloc(c, &c->w_rel, Vd));
   RGCN_TRY(dmalloc(c, &c->g_rel, Vd));
   add_param(c, "W_relation", {(int64_t)V, (int64_t)d}, c->w_rel, c->g_rel, LAYOUT_PLAIN);
-  if (c->fuse < 0 || c->fuse > 2) c->fuse = 0;
+  if (c->fuse < 0 || c->fuse > 3) c->fuse = 0;
   c->H.assign(c->L + 1, nullptr);
   for (int l = 0; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->H[l], Vd));
   RGCN_TRY(dmalloc(c, &c->self_buf, Vd));
@@ -543,6 +543,11 @@ static bool fused_layer(const rgcn_ctx* c) {
 
 // The block layer as ONE pass over the incidence CSR (block_spmm.hip): block kind, one GPU, weight table in LDS.
 static bool spmm_layer(const rgcn_ctx* c) { return c->fuse == 2 && block_spmm_available(c); }
+// ... destination-major, one column band per XCD, weights through L2 (block_rows.hip): block kind, one GPU.
+static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 3 && block_rows_available(c); }
+static rgcn_status single_pass(rgcn_ctx* c, const char* tag, int l, bool backward, const float* X, const CombineArgs& a) {
+  return rows_layer(c) ? block_rows(c, tag, l, backward, X, a) : block_spmm(c, tag, l, backward, X, a);
+}
 
 static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
@@ -551,7 +556,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
-  if (spmm_layer(c)) {
+  if (spmm_layer(c) || rows_layer(c)) {
     // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
     // the incidence CSR (no message buffer)
     RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, V, d, d, Hin, d, c->layers[l].wself, d, c->self_buf, d, 1));
@@ -562,7 +567,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     a.row_lo = 0; a.row_hi = V;
     a.drop = make_drop(c, l, true);
     a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(block_spmm(c, "block_spmm_fwd", l, false, Hin, a));
+    RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_fwd" : "block_spmm_fwd", l, false, Hin, a));
   } else if (fused_layer(c)) {
     // messages -> ONE kernel: H' = relu(dropout(H.W_self) + sum of the row's messages)
     RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
@@ -690,7 +695,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(stream_join(c, 0));
     c->dw_pending = false;
   }
-  if (spmm_layer(c)) {
+  if (spmm_layer(c) || rows_layer(c)) {
     // weight gradients of the relations (dW_r = sum n g (x) x, relation-major, two row gathers per message) on side
     // stream 0 beside the self-loop GEMMs; the row gradients come from the single-pass kernel behind G = dS . W_self^T
     {
@@ -705,7 +710,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, V, Hin, d, c->bwd_dS, d, lb.gwself, d,
                         auto_split_k(d, d, V)));
     }
-    RGCN_TRY(block_spmm(c, "block_spmm_bwd", l, true, c->bwd_D, a));
+    RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
   } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
     // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
@@ -1421,6 +1426,8 @@ rgcn_status rgcn_graph_launch(rgcn_ctx* c, int32_t graph_id) {
     RGCN_FAIL(c, RGCN_ERR_INVALID, "unknown graph id");
   RGCN_HIP(c, hipGraphLaunch(c->graphs[graph_id], c->main_stream));
   c->fwd_done = true;       // the replayed steps leave activations / gradients of their last step behind
+  c->weights_version += 1;  // a replayed train step moved the weights behind the host's back: derived weight tables
+                            // (block_spmm / block_rows) built before the replay are stale for uncaptured passes
   return RGCN_OK;
 }
 
@@ -1605,7 +1612,7 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
 
 rgcn_status rgcn_set_fusion(rgcn_ctx* c, int32_t mode) {
   RGCN_NEED(c);
-  if (mode < 0 || mode > 2) RGCN_FAIL(c, RGCN_ERR_INVALID, "fusion mode must be 0, 1 or 2");
+  if (mode < 0 || mode > 3) RGCN_FAIL(c, RGCN_ERR_INVALID, "fusion mode must be 0, 1, 2 or 3");
   c->fuse = mode;
   return RGCN_OK;
 }

@@ -41,15 +41,37 @@ void set_global_error(const std::string& s);
 
 // ---------------------------------------------------------------- dropout generator
 // Counter-based Bernoulli(keep) draw: nothing is stored, forward and backward re-derive the same
-// bit from (seed, layer, flat element index).  splitmix64 finaliser; top 24 bits compared with
-// keep_prob * 2^24.  Statistically equivalent to tf.nn.dropout's floor(keep + U[0,1))
+// bit from (seed, layer, flat element index).  Statistically equivalent to tf.nn.dropout's floor(keep + U[0,1))
 // (message_gcn.py:64); the exact TF Philox stream is not reproducible (parity tests inject masks).
-__host__ __device__ inline uint32_t drop_bits(uint64_t seed, uint32_t layer, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + ((uint64_t)layer << 44) + 1ull);
+// drop_bits (splitmix64 per draw, 24 bits out) serves the negative sampler; the dropout masks use the two-stage form
+// below since round 4: a 64-bit key per (seed, layer) from splitmix64 -- uniform over a launch -- and a 32-bit
+// two-multiply hash per element keyed at both rounds (9 VALU operations instead of ~40: the per-element 64-bit
+// multiplies were a third of the VALU work of the single-pass layer kernels); keep iff the top 24 bits < keep * 2^24.
+__host__ __device__ inline uint64_t splitmix64_mix(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= (z >> 31);
-  return (uint32_t)(z >> 40);
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint32_t drop_bits(uint64_t seed, uint32_t layer, uint64_t idx) {
+  return (uint32_t)(splitmix64_mix(seed + 0x9E3779B97F4A7C15ull * (idx + ((uint64_t)layer << 44) + 1ull)) >> 40);
+}
+struct DropKey {
+  uint32_t k0, k1;
+};
+__host__ __device__ inline DropKey drop_key_of(uint64_t seed, uint32_t layer) {
+  const uint64_t z = splitmix64_mix(seed + 0x9E3779B97F4A7C15ull * (((uint64_t)layer << 44) + 1ull));
+  return DropKey{(uint32_t)z, (uint32_t)(z >> 32)};
+}
+__host__ __device__ inline uint32_t drop_bits24(const DropKey& k, uint64_t idx) {
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  uint32_t x = (uint32_t)idx ^ k.k0 ^ ((hi << 16) | (hi >> 16));
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x += k.k1;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x >> 8;
 }
 
 enum DropMode { DROP_NONE = 0, DROP_RNG = 1, DROP_MASK = 2 };
@@ -73,13 +95,18 @@ struct DropSpec {
 };
 
 #if defined(__HIPCC__)
+// the (seed, layer) key of a launch's dropout spec; derive it ONCE per thread, outside the element loops
+__device__ __forceinline__ DropKey drop_key(const DropSpec& ds) {
+  if (ds.mode != DROP_RNG) return DropKey{0u, 0u};
+  return drop_key_of(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer);
+}
 // dropout factor of flat element idx: 1/keep or 0 (1 when the spec is inactive)
-__device__ __forceinline__ float drop_factor(const DropSpec& ds, size_t idx) {
+__device__ __forceinline__ float drop_factor(const DropSpec& ds, const DropKey& key, size_t idx) {
   if (ds.mode == DROP_NONE) return 1.0f;
-  if (ds.mode == DROP_RNG)
-    return drop_bits(ds.seed + (ds.seed_offset ? *ds.seed_offset : 0ull), ds.layer, idx) < ds.thresh ? ds.inv_keep : 0.0f;
+  if (ds.mode == DROP_RNG) return drop_bits24(key, idx) < ds.thresh ? ds.inv_keep : 0.0f;
   return ds.mask[idx] ? ds.inv_keep : 0.0f;
 }
+__device__ __forceinline__ float drop_factor(const DropSpec& ds, size_t idx) { return drop_factor(ds, drop_key(ds), idx); }
 #endif
 
 // What k_combine does behind the self-loop GEMM, fused into the GEMM's own epilogue (gemm_bf16x3.hip): the product
@@ -145,6 +172,10 @@ struct LayerBufs {
   // weights version it was built from
   float* wbm = nullptr;
   uint64_t wbm_version = ~0ull;
+  // BLOCK, destination-major banded layer kernel (block_rows.hip): band-tiled copy of wrel,
+  // [2R][8 bands][ceil(sd*sd/4)][GW lanes][4], allocated at first use
+  float* wtile = nullptr;
+  uint64_t wtile_version = ~0ull;
 };
 
 struct GraphBufs {
@@ -163,6 +194,11 @@ struct GraphBufs {
   int32_t* ngiant = nullptr;
   int32_t giant_cap = 0, piece_cap = 0;
   bool giant_on = false;        // this graph was prepared with the giant-row cut enabled
+  // rows ordered by DESCENDING number of slots, long / giant rows last (block kind, one GPU: the destination-major
+  // layer kernel hands the four lane groups of a wavefront rows of equal length); row_key[v] = 32 - slots (33: long)
+  uint32_t *row_key = nullptr, *row_key_s = nullptr;
+  int32_t* row_order = nullptr;
+  uint16_t* row_tab = nullptr;
   int32_t* nlong = nullptr;     // device counter (lives in the zero-initialised counter block)
   int32_t long_cap = 0;
   int32_t* rel_ptr = nullptr;   // [2R+1]
@@ -288,7 +324,8 @@ struct rgcn_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
   // block kind, one GPU: 0 = message kernel + k_combine (two kernels, [2E,d] message buffer), 1 = self-loop GEMM with
-  // the combine as its epilogue, 2 = single-pass block SpMM (block_spmm.hip; no message buffer at all)
+  // the combine as its epilogue, 2 = single-pass block SpMM (block_spmm.hip; no message buffer at all), 3 = the
+  // destination-major banded single-pass layer (block_rows.hip; no message buffer, weights through L2)
   int fuse = 0;
   uint64_t weights_version = 1;           // bumped whenever a parameter value changes (set_param, Adam)
   bool dw_pending = false;                // a dW-only message-gradient kernel of the previous backward layer is still on side stream 0
@@ -448,6 +485,11 @@ bool block_spmm_available(const rgcn_ctx* c);
 size_t block_spmm_weight_floats(const rgcn_ctx* c);
 rgcn_status block_spmm(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca);
 
+// ---- block_rows.hip: the block layer destination-major in ONE pass per direction, one column band per XCD, weights
+// through L2 (no LDS table, no message buffer); bitwise equal to the two-kernel form
+bool block_rows_available(const rgcn_ctx* c);
+rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca);
+
 // ---- basis.hip
 rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z);
 struct CombineArgs;
@@ -484,6 +526,8 @@ struct CombineArgs {
   DropSpec drop2;        // applied to out2
 };
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
+// giant rows only: prologue + the pieces in GraphBufs' piece slab (written by the caller's own kernel) + epilogue
+rgcn_status combine_giant_finish(rgcn_ctx* c, const CombineArgs& a);
 rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
 rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds);
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols);

@@ -629,13 +629,16 @@ def test_rccl_single_rank_communicator(native):
 
 # ------------------------------------------------------------------ fused layer kernels == the two-kernel form
 @pytest.mark.parametrize("V,R,d,nb,E,hubs", [(300, 12, 20, 4, 2500, 3), (97, 5, 8, 2, 400, 1), (64, 3, 16, 4, 0, 0),
-                                             (2000, 30, 500, 100, 6000, 4), (1100, 7, 24, 3, 9000, 2), (600, 4, 9, 9, 3000, 1)])
+                                             (2000, 30, 500, 100, 6000, 4), (1100, 7, 24, 3, 9000, 2), (600, 4, 9, 9, 3000, 1),
+                                             (400, 6, 170, 170, 3000, 2), (350, 5, 300, 300, 2500, 1)])
 @pytest.mark.parametrize("gen_dropout", [False, True])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, hubs, gen_dropout, mode):
-    """rgcn_set_fusion: mode 1, the self-loop GEMM with the combine as its epilogue, and mode 2, the single-pass block
+    """rgcn_set_fusion: mode 1, the self-loop GEMM with the combine as its epilogue, mode 2, the single-pass block
     SpMM (gather + sd x sd products + segmented row sums + self-loop term + dropout + relu in ONE kernel per layer and
-    direction, no message buffer), against mode 0 (message kernel + k_combine) -- same products, same summation order:
+    direction, no message buffer), and mode 3, the destination-major banded single pass (block_rows.hip: one column band
+    per XCD, a lane group per (row, band), long rows by one wavefront each; group widths 8 / 16 / 32 / 64 lanes at
+    nb <= 64 / 100 / 170 / 300) against mode 0 (message kernel + k_combine) -- same products, same summation order:
     every activation and every gradient BITWISE equal, with hub rows (more than 32 slots: eight interleaved lanes),
     rows spanning several slot tiles, injected and generated dropout, an empty graph, sd in {1, 3, 4, 5, 8}"""
     if mode == 1 and d % 4 != 0:
@@ -675,7 +678,7 @@ def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
     params, triples, masks, dcodes = make_case(V, R, d, 2, "block", nb, E, seed=5)
     triples[np.random.RandomState(2).choice(E, 6000, replace=False), 2] = 7
     out = []
-    for fuse in (2, 0):
+    for fuse in (2, 3, 0):
         with native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=E) as eng:
             eng.set_fusion(fuse)
             eng.set_params(params)
@@ -684,9 +687,10 @@ def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
             codes = eng.codes()
             eng.backward(dcodes)
             out.append((codes, eng.get_grads()))
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    for k in out[0][1]:
-        np.testing.assert_array_equal(out[0][1][k], out[1][1][k], err_msg=k)
+    for form in (0, 1):
+        np.testing.assert_array_equal(out[form][0], out[2][0])
+        for k in out[form][1]:
+            np.testing.assert_array_equal(out[form][1][k], out[2][1][k], err_msg=k)
     # 2R x sd^2 floats = 2 * 3000 * 25 * 4 B = 600 KB: no LDS table -> form 0 under the hood, still correct
     V, R, d, nb, E = 200, 3000, 10, 2, 500
     params, triples, masks, dcodes = make_case(V, R, d, 1, "block", nb, E, seed=6)
