@@ -378,16 +378,19 @@ rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises *
 rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
 
 /* Form of the block-diagonal layer (ConcatGcn.compute_messages + combine_messages, gcn_basis_concat.py:35-83, and
- * their gradient) on one GPU; RGCN_FUSE in the environment sets it at create.  All three give bitwise the same
+ * their gradient) on one GPU; RGCN_FUSE in the environment sets it at create.  All four give bitwise the same
  * activations and gradients (tests/test_gpu_parity.py::test_fused_layer_kernel_equals_the_two_kernel_form).
- *   0 : (default) relation-major message kernel -> [2E,d] message buffer -> row-major reduce (k_combine)
+ *   3 : (default since round 4) destination-major banded single pass (csrc/block_rows.hip): ONE kernel per layer and
+ *       direction walks the incidence CSR -- a 16-lane group per (row, column band), one band per XCD, the relation's
+ *       sd x sd blocks read through L2 from a band-tiled copy of the weights, rows taken by descending length, long
+ *       rows by whole workgroups through LDS tiles -- and applies self-loop term, dropout and relu / relu'; no message
+ *       buffer.  39 / 46 us per layer forward / backward against 57 / 74 for form 0 at FB15k-237 minibatch size, half
+ *       the time at the 272,115-edge training graph (profiles/r04_rowmajor_spmm_ab.md).
+ *   0 : relation-major message kernel -> [2E,d] message buffer -> row-major reduce (k_combine)
  *   1 : as 0, with the reduce as the epilogue of the self-loop GEMM (the product never travels; measured slower)
- *   2 : the single-pass block SpMM (csrc/block_spmm.hip): ONE kernel per layer and direction gathers the partner rows
- *       through the incidence CSR, applies the sd x sd blocks from an LDS-resident weight table (needs 2R x sd^2 floats
- *       of LDS: up to ~500 relations at sd = 5), reduces each row's messages in k_combine's order and applies self-loop
- *       term, dropout and relu / relu' -- no message buffer at all, 60 % less HBM traffic, and on MI355X 2.2x SLOWER
- *       than form 0 (instruction- and latency-bound at 8 waves per CU; profiles/r03_block_spmm_ab.md), hence opt-in.
- * Other kinds, sharded contexts and weight tables that do not fit run form 0 whatever the setting. */
+ *   2 : round 3's single pass (csrc/block_spmm.hip): per-block workgroups, LDS-resident weight table (needs 2R x sd^2
+ *       floats of LDS), 20-byte gathers; 2.4x slower than form 0 at minibatch scale, 3.7x at 272 k edges.
+ * Other kinds and sharded contexts run form 0 whatever the setting. */
 rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t mode);
 
 /* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.

@@ -360,14 +360,15 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   {
     const char* e = getenv("RGCN_STREAMS");
     c->use_aux = !(e && atoi(e) == 0);
-    // Off by default: measured on MI355X (profiles/r02_fused_layer_ab.log) the fused kernel takes 87-89 us where GEMM +
-    // combine take 80-83 -- all workgroups reach the gather epilogue at once, with 8 waves per CU where k_combine runs
-    // 32 -- although it moves 58 MB less per layer pass.  RGCN_FUSE=1 / rgcn_set_fusion turn it on.
-    // RGCN_FUSE = 0 / 1 / 2 picks the form of the block layer (rgcn_set_fusion).  Default 0, the two-kernel form: both
-    // fused forms are bitwise equal to it and both measured slower on MI355X (profiles/r02_fused_layer_ab.log: GEMM
-    // epilogue 87-89 us against 80-83; profiles/r03_block_spmm_ab.md: single-pass SpMM 125-160 us against 57 forward)
+    // RGCN_FUSE = 0 / 1 / 2 / 3 picks the form of the block layer (rgcn_set_fusion); all four are bitwise equal.
+    // Default since round 4: 3, the destination-major banded single pass (block_rows.hip) -- no message buffer, weights
+    // through L2: 39-41 us forward / 46-48 backward per layer against 57 / 75 for the two-kernel form 0 at FB15k-237
+    // minibatch size, 0.39 ms against 0.77 per layer pass at the 272,115-edge training graph
+    // (profiles/r04_rowmajor_spmm_ab.md).  Forms 1 (GEMM-epilogue fusion: 87-89 us against 80-83, profiles/r02_fused_
+    // layer_ab.log) and 2 (per-block workgroups + LDS weight table: 125-160 us, profiles/r03_block_spmm_ab.md) stay
+    // opt-in; sharded contexts and the basis kind run form 0 whatever the setting.
     const char* fu = getenv("RGCN_FUSE");
-    c->fuse = fu ? atoi(fu) : 0;
+    c->fuse = fu ? atoi(fu) : 3;
     const char* m = getenv("RGCN_GEMM_MODE");
     const int mode = m ? atoi(m) : 6;
     c->gemm_mode = (mode == 0 || mode == 3 || mode == 6 || mode == 9) ? mode : 6;

@@ -34,6 +34,14 @@
 
 #include "rgcn_internal.h"
 
+#ifndef ROWS_MW
+#define ROWS_MW 1
+#endif
+// experiment builds only (tools/gpu_rows_variants.sh; WRONG results): 1 no dropout hash, 2 no weight loads, 4 no x
+// loads, 8 no products, 16 no stores, 32 no slot-index loads
+#ifndef ROWS_ABL
+#define ROWS_ABL 0
+#endif
 
 namespace rgcn {
 
@@ -66,6 +74,7 @@ struct RowsArgs {
   int32_t V, d, nb, relu, row_lo, row_hi;
   int32_t n_long_wg;         // workgroups per band that walk the long-row / piece lists (they lead the grid)
   int32_t rows_per_wg;       // rows of one short-row workgroup
+  int32_t ablate;            // diagnostics (RGCN_ROWS_ABLATE): 1 = long rows skipped, 2 = short rows skipped (WRONG results)
 };
 
 constexpr int kRowsThreads = 256;
@@ -115,7 +124,7 @@ __device__ __forceinline__ void load_w(const float4* __restrict__ wq, int rl, fl
   const float4* wp = wq + (size_t)rl * (8 * NT * GW);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const float4 q = wp[t * GW];
+    const float4 q = (ROWS_ABL & 2) ? make_float4(nr, nr + 1.f, nr + 2.f, nr + 3.f) : wp[t * GW];
     r.w[4 * t] = q.x;
     if (4 * t + 1 < SD * SD) r.w[4 * t + 1] = q.y;
     if (4 * t + 2 < SD * SD) r.w[4 * t + 2] = q.z;
@@ -126,6 +135,12 @@ __device__ __forceinline__ void load_w(const float4* __restrict__ wq, int rl, fl
 // the lane's sd inputs of partner row pv (4 sd bytes of the row's 16 GW-lane band piece)
 template <int SD>
 __device__ __forceinline__ FloatN<SD> load_x(const RowsArgs& a, int pv, int col) {
+  if (ROWS_ABL & 4) {
+    FloatN<SD> r;
+#pragma unroll
+    for (int i = 0; i < SD; ++i) r.v[i] = (float)(pv + i);
+    return r;
+  }
   return *reinterpret_cast<const FloatN<SD>*>(a.X + (size_t)pv * a.d + col);
 }
 
@@ -133,6 +148,11 @@ __device__ __forceinline__ FloatN<SD> load_x(const RowsArgs& a, int pv, int col)
 template <int SD, bool BWD>
 __device__ __forceinline__ void slot_value(const SlotRegs<SD>& r, const FloatN<SD>& x, float (&y)[SD]) {
 #pragma clang fp contract(off)
+  if (ROWS_ABL & 8) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) y[i] = x.v[i] + r.w[i] + r.w[SD * SD - 1 - i];
+    return;
+  }
   if constexpr (!BWD) {
 #pragma unroll
     for (int i = 0; i < SD; ++i) {
@@ -173,7 +193,7 @@ __device__ __forceinline__ void row_open(const RowsArgs& a, int v, size_t off, R
 // the lane's sd dropout factors: ONE (uniform) dispatch on the spec's mode for all of them
 template <int SD>
 __device__ __forceinline__ void drop_factors(const DropSpec& ds, const DropKey& k, size_t off, float (&f)[SD]) {
-  if (ds.mode == DROP_RNG) {
+  if (ds.mode == DROP_RNG && !(ROWS_ABL & 1)) {
 #pragma unroll
     for (int i = 0; i < SD; ++i) f[i] = drop_bits24(k, off + i) < ds.thresh ? ds.inv_keep : 0.0f;
   } else if (ds.mode == DROP_MASK) {
@@ -226,7 +246,7 @@ __device__ __forceinline__ void row_epilogue(const RowsArgs& a, const DropKey& k
 }
 template <int SD>
 __device__ __forceinline__ void row_store(const RowsArgs& a, const RowOut<SD>& out) {
-  if (out.store) {
+  if (out.store && (!(ROWS_ABL & 16) || out.o.v[0] == 12345.678f)) {
     *reinterpret_cast<FloatN<SD>*>(a.out + out.off) = out.o;
     if (a.out2 != nullptr) *reinterpret_cast<FloatN<SD>*>(a.out2 + out.off) = out.o2;
   }
@@ -344,7 +364,7 @@ __device__ __forceinline__ void wg_long_sum(const RowsArgs& a, int beg, int end,
 }
 
 template <int SD, bool BWD, int GW>
-__global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
+__global__ void __launch_bounds__(kRowsThreads, ROWS_MW) k_block_rows(RowsArgs a) {
 #pragma clang fp contract(off)
   constexpr int NG = 64 / GW;
   __shared__ float ybuf[LongTile<SD, GW>::TS * GW * SD];
@@ -364,6 +384,7 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   key2.k0 = __builtin_amdgcn_readfirstlane(key2.k0); key2.k1 = __builtin_amdgcn_readfirstlane(key2.k1);
   if (j < a.n_long_wg) {
     // ---- long rows and giant-row pieces: one workgroup each
+    if (a.ablate == 1) return;
     const bool writer = threadIdx.x < GW && lane_ok;
     const int n = *a.nlong;
     for (int idx = j; idx < n; idx += a.n_long_wg) {
@@ -407,6 +428,7 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   // idle on its longest row (in vertex order 59 % of the lane-slots were idle), and the heavy workgroups start first.
   // A wavefront owns RW consecutive positions: row ids and row pointers of all its turns come with two coalesced loads,
   // the slot indices of turn t + 1 are fetched under the messages of turn t.
+  if (a.ablate == 2) return;
   // Turn t of wavefront W (of NW) takes the NG consecutive positions (t NW + W) NG ..: the rows of a turn are
   // neighbours in the sorted order (equal lengths), the turns of a wavefront are dealt from the whole order like
   // cards -- every wavefront gets its share of heavy and of light rows (contiguous chunks of the sorted order left the
@@ -433,6 +455,7 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   struct Idx { int pv, rl; float nr; };
   auto fetch_idx = [&](int beg, int n, int c0, Idx& r) {
     const bool ok = c0 + li < n;                        // this group's next GW slot indices, one coalesced load per array
+    if (ROWS_ABL & 32) { r.pv = (beg + c0 + li) & 8191; r.rl = (beg + li) & 255; r.nr = 0.5f; return; }
     r.pv = ok ? a.slot_v[beg + c0 + li] : 0;
     r.rl = ok ? a.slot_rel[beg + c0 + li] : 0;
     r.nr = ok ? a.slot_norm[beg + c0 + li] : 0.0f;
@@ -581,6 +604,8 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
     rpw = std::max(quantum, std::min(256, rpw / quantum * quantum));
     a.rows_per_wg = rpw;
   }
+  static const int ablate_env = getenv("RGCN_ROWS_ABLATE") ? atoi(getenv("RGCN_ROWS_ABLATE")) : 0;
+  a.ablate = ablate_env;
   // one workgroup per long row and turn: about one per 256 slots of the graph, 32 .. 1024 workgroups per band
   int64_t want = lwg_env > 0 ? lwg_env : (2 * c->g.E) / 256;
   a.n_long_wg = c->g.E > 0 ? (int)std::max<int64_t>(32, std::min<int64_t>(1024, want)) : 0;
@@ -599,7 +624,11 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
 #define RGCN_ROWS_CASE(SDV) \
   case SDV: e = launch_rows_gw<SDV>(c, a, backward, grid, gw); break;
   switch (c->sd) {
+#ifdef ROWS_ONLY_SD5
+    RGCN_ROWS_CASE(5)
+#else
     RGCN_ROWS_CASE(1) RGCN_ROWS_CASE(2) RGCN_ROWS_CASE(3) RGCN_ROWS_CASE(4) RGCN_ROWS_CASE(5) RGCN_ROWS_CASE(8)
+#endif
     default: RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "block size d/nb must be one of 1,2,3,4,5,8");
   }
 #undef RGCN_ROWS_CASE

@@ -5,9 +5,9 @@ TAG=${1:-v}; shift
 mkdir -p gpurun_out; export TMPDIR=/tmp
 i=0
 for v in "" "$@"; do
-  RGCN_EXTRA_HIPCC_FLAGS="$v" python -c "from relationprediction_amd import build; build.build()" 2>&1 | grep -v "not a recognized" | tail -2
-  for wl in fb237_block fb237_block_traingraph; do
-  RGCN_FUSE=3 timeout 300 python bench.py --workload $wl --steps 30 --warmup 5 --cpu-steps 0 --no-extra-workloads --no-fp32-reference --no-live-traffic > gpurun_out/var_${TAG}_$i.json 2> gpurun_out/var_${TAG}_$i.err
+  RGCN_EXTRA_HIPCC_FLAGS="$v $BASEFLAGS" python -c "from relationprediction_amd import build; build.build()" 2>&1 | grep -v "not a recognized" | tail -2
+  for wl in ${WLS:-fb237_block fb237_block_traingraph}; do
+  env RGCN_FUSE=3 $RUNENV timeout 300 python bench.py --workload $wl --steps 30 --warmup 5 --cpu-steps 0 --no-extra-workloads --no-fp32-reference --no-live-traffic > gpurun_out/var_${TAG}_$i.json 2> gpurun_out/var_${TAG}_$i.err
   python - <<PY
 import json
 d = json.load(open("bench_details.json"))
