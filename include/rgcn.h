@@ -33,6 +33,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define RGCN_ABI_VERSION 1
 
@@ -418,6 +422,9 @@ rgcn_status rgcn_profile_get(rgcn_ctx* ctx, int32_t i, char* name, int32_t name_
                              double* total_ms, double* alg_bytes, double* alg_flops);
 rgcn_status rgcn_profile_get_compulsory(rgcn_ctx* ctx, int32_t i, double* compulsory_bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- the dense contractions on their own (GPU parity tests of the GEMM kernels, tools/gemm_*.py) ---- */
 /* C[M,N] = op(A) . op(B) through the library's fp32-MFMA GEMM.  trans_a == 0: A is [M,K] row-major,
@@ -26,6 +30,9 @@ rgcn_status rgcn_debug_gemm_time(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b
                                  int32_t K, int32_t split_k, int32_t iters, const float* a_host,
                                  const float* b_host, float* avg_ms);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -160,6 +160,10 @@ def load_library(path=None, devtools=False):
         return _lib_devtools
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get("RGCN_LIBRARY") == "devtools":
+        # the multi-process tests run their ranks on the devtools build: only that one honours RGCN_RCCL_LIBRARY
+        _lib = load_library(devtools=True)
+        return _lib
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise ImportError(

@@ -28,14 +28,17 @@ SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "ge
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "neighborhood.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(ROOT, "include", "rgcn.h"),
            os.path.join(ROOT, "include", "rgcn_devtools.h")]
-DEVTOOLS_SOURCES = ["rgcn_api.hip"]       # the only translation unit the flag changes
+DEVTOOLS_SOURCES = ["rgcn_api.hip", "comm.hip"]       # the translation units the flag changes
 # No packed-FP32 VALU instructions anywhere in the library: on gfx950 a v_pk_fma_f32 (and kin) issued
 # by a wave that shares a CU with waves issuing v_mfma_f32_32x32x16_bf16 returns wrong low halves
 # (reproducer: tools/mfma_corun.hip).  The encoder runs its HBM-bound kernels on side
 # streams beside the bf16-split GEMM, so the feature is switched off for the device compile (the host
 # pass prints "not a recognized feature" and ignores it) and the linked code objects are checked.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
+# -fvisibility=hidden: the library exports the C ABI of include/rgcn.h (whose declarations carry default visibility) and
+# nothing else -- none of the C++ internals (tests/test_abi.py checks the dynamic symbol table)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+         "-Wno-unused-function"] + NO_PACKED_FP32
 # experiment knobs of throw-away builds (tools/*_ab.sh): extra -D flags, part of the object digest
 FLAGS += [f for f in os.environ.get("RGCN_EXTRA_HIPCC_FLAGS", "").split() if f]
 
@@ -128,7 +131,12 @@ def build(force=False, verbose=False):
     for lib, objs in ((LIB, [j[1] for j in product]),
                       (LIB_DEVTOOLS, [devobj.get(os.path.basename(j[0]), j[1]) for j in product])):
         if force or stale or not os.path.exists(lib):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
+            # version script: whatever weak template instantiations the objects still carry (std::vector members ...)
+            # stay local -- the dynamic symbol table is the C ABI alone
+            vs = os.path.join(OBJDIR, "exports.map")
+            with open(vs, "w") as f:
+                f.write("{ global: rgcn_*; local: *; };\n")
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", lib] + objs + ["-ldl"]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("link failed:\n" + r.stderr[-4000:])

@@ -40,8 +40,9 @@ Rccl& rccl() {
 bool load_rccl(std::string* err) {
   Rccl& r = rccl();
   if (r.handle) return true;
-  // RGCN_RCCL_LIBRARY names another library with the same five entry points (the multi-process tests use it to
-  // put several ranks on one GPU, which RCCL refuses); it is bound privately, never ahead of a real RCCL
+#ifdef RGCN_DEVTOOLS
+  // librgcn_devtools.so only (a test seam, not in the product library): RGCN_RCCL_LIBRARY names another library with the
+  // same entry points -- the multi-process tests use it to put several ranks on one GPU, which RCCL refuses
   if (const char* over = getenv("RGCN_RCCL_LIBRARY")) {
     r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
     if (!r.handle) {
@@ -49,6 +50,7 @@ bool load_rccl(std::string* err) {
       return false;
     }
   }
+#endif
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     if (r.handle) break;

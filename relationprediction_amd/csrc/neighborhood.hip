@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_nbr_offsets(const DrawParams* __restri
     if (tid == 0) carry_s = carry + total;
     __syncthreads();
   }
-  if (tid == 0 && (int)carry_s != p->k) atomicOr(errflag, 8);
+  if (tid == 0 && (int)carry_s != p->k) atomicOr(errflag, 32);   // (not a diameter problem: its own flag and message)
 }
 // the chosen edges' rows, in edge order, to the caller's batch buffer
 __global__ void __launch_bounds__(kCompactBlock) k_nbr_write(const DrawParams* __restrict__ p, const int32_t* __restrict__ tri,
@@ -352,6 +352,7 @@ void neighborhood_free(rgcn_ctx* c) {
   if (q.draw_exec) (void)hipGraphExecDestroy(q.draw_exec);
   if (q.draw_graph) (void)hipGraphDestroy(q.draw_graph);
   if (q.capture_stream) (void)hipStreamDestroy(q.capture_stream);
+  if (q.ev_draw) (void)hipEventDestroy(q.ev_draw);
   q = NeighborhoodBufs();
 }
 
@@ -548,6 +549,11 @@ rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t k64, uint64_t seed, int32_t
     }
   }
   hipStream_t st = c->stream;
+  // The draw's state is shared by every draw of the context.  Same stream: stream order.  Other stream (the driver
+  // draws batch 1 on the main stream and, at once, batch 2 on the prefetch stream): wait for the previous draw's end
+  // BEFORE this draw's parameters overwrite the ones its kernels still read.
+  if (!q.ev_draw) RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_draw, hipEventDisableTiming));
+  if (q.last_draw_stream != nullptr && q.last_draw_stream != st) RGCN_HIP(c, hipStreamWaitEvent(st, q.ev_draw, 0));
   if (any_full)
     RGCN_TRY(rgcn_copy_to_device_async(c, q.comp_state, q.comp_state_h.data(), (int64_t)q.ncomp, on_prefetch_stream ? 1 : 0));
   DrawParams dp;
@@ -563,6 +569,8 @@ rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t k64, uint64_t seed, int32_t
   if (!q.draw_exec) RGCN_TRY(record_draw(c));
   ProfScope ps(c, "nbr_sample", 8.0 * 2.0 * n * 12 + 32.0 * n, 0, 12.0 * n + 12.0 * k);
   RGCN_HIP(c, hipGraphLaunch(q.draw_exec, st));
+  RGCN_HIP(c, hipEventRecord(q.ev_draw, st));
+  q.last_draw_stream = st;
   return RGCN_OK;
 }
 

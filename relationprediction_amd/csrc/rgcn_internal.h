@@ -285,6 +285,10 @@ struct NeighborhoodBufs {
   hipGraph_t draw_graph = nullptr;       // the kernels of one draw, recorded once, replayed per draw
   hipGraphExec_t draw_exec = nullptr;
   hipStream_t capture_stream = nullptr;
+  // one set of per-draw state (params, distances, keys, select state, the graph) serves draws on the main AND the
+  // prefetch stream: a draw on the other stream waits for the previous draw's end
+  hipEvent_t ev_draw = nullptr;
+  hipStream_t last_draw_stream = nullptr;
   // host side (components are a property of the graph: found once, at reserve)
   std::vector<int32_t> comp_h;           // [V]
   std::vector<int64_t> comp_edges_h;     // [ncomp] edges per component

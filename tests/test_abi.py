@@ -36,6 +36,29 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert lib.rgcn_abi_version() == 1
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-2] in "TtDdBbRrWwVv")
+
+
+def test_library_exports_nothing_but_the_header(lib_path):
+    """-fvisibility=hidden + default visibility on include/rgcn.h's declarations: the dynamic symbol table of
+    librgcn.so is the header's names and NOTHING else (round 3 exported 63 mangled C++ internals beside them); the
+    devtools build adds include/rgcn_devtools.h's names only.  The collective-library override (RGCN_RCCL_LIBRARY) is a
+    seam of the devtools build: the product library does not even contain the string."""
+    from relationprediction_amd import build
+    ignore = {"_init", "_fini", "__bss_start", "_edata", "_end", "__hip_fatbin", "__hip_fatbin_wrapper"}
+    got = [x for x in _dynamic_symbols(lib_path) if x not in ignore and not x.startswith("__hip_")]
+    assert got == declared_symbols(), sorted(set(got) ^ set(declared_symbols()))
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgcn_devtools.h")).read(), flags=re.S)
+    dev = set(re.findall(r"\b(rgcn_[a-z_0-9]+)\s*\(", text))
+    got_dev = [x for x in _dynamic_symbols(build.LIB_DEVTOOLS) if x not in ignore and not x.startswith("__hip_")]
+    assert got_dev == sorted(set(declared_symbols()) | dev), sorted(set(got_dev) ^ (set(declared_symbols()) | dev))
+    assert b"RGCN_RCCL_LIBRARY" not in open(lib_path, "rb").read()
+    assert b"RGCN_RCCL_LIBRARY" in open(build.LIB_DEVTOOLS, "rb").read()
+
+
 def test_binding_matches_header(lib_path):
     from relationprediction_amd import _native
     assert _native.exported_symbols() == declared_symbols()

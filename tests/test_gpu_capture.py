@@ -194,13 +194,21 @@ def test_config5_fb15k_train_step_in_a_hipgraph(native):
 
 
 def test_capture_on_a_sharded_context_needs_its_communicator(native):
-    """BASELINE config 5 asks for a captured train step on 8 GPUs.  Capture on a world > 1 context is allowed (the
-    collectives inside the graph are exercised by test_gpu_multiprocess.py::test_captured_sharded_train_step); a step
-    without a communicator still fails inside the capture as it does outside, and the capture can be ended."""
+    """BASELINE config 5 asks for a captured train step on 8 GPUs.  Capture on a world > 1 context is EXPERIMENTAL (the
+    collectives inside the graph are exercised with stand-in collectives on one GPU only,
+    test_gpu_multiprocess.py::test_captured_sharded_train_step) and opt-in: refused by name without
+    RGCN_CAPTURE_SHARDED=1; with it, a step without a communicator still fails inside the capture as it does outside,
+    and the capture can be ended."""
+    import os
     eng = native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2)
+    old = os.environ.pop("RGCN_CAPTURE_SHARDED", None)
     try:
         tri = eng.to_device(np.array([[0, 1, 2], [3, 0, 4]], dtype=np.int32))
         dc = eng.to_device(np.zeros((40, 8), dtype=np.float32))
+        with pytest.raises(native.RgcnError) as err:
+            eng.capture_begin()
+        assert "RGCN_CAPTURE_SHARDED=1" in str(err.value)
+        os.environ["RGCN_CAPTURE_SHARDED"] = "1"
         eng.capture_begin()
         with pytest.raises(native.RgcnError) as err:
             eng.step_device(tri, 2, dc, train=True, seed=1)
@@ -212,6 +220,9 @@ def test_capture_on_a_sharded_context_needs_its_communicator(native):
         tri.free(); dc.free()
     finally:
         eng.close()
+        os.environ.pop("RGCN_CAPTURE_SHARDED", None)
+        if old is not None:
+            os.environ["RGCN_CAPTURE_SHARDED"] = old
 
 
 def test_context_destroyed_in_mid_capture_leaves_usable_streams(native):

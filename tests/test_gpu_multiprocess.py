@@ -26,6 +26,7 @@ def collective():
 def launch(nproc, port, script_args, collective, extra_env=None, timeout=240):
     env = dict(os.environ)
     env["RGCN_RCCL_LIBRARY"] = collective
+    env["RGCN_LIBRARY"] = "devtools"        # the collective override is a seam of librgcn_devtools.so only
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
@@ -85,7 +86,7 @@ def test_bench_spawns_its_own_ranks_without_a_launcher(collective, world):
     """`python3 bench.py --gpus N` as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the script starts
     its N ranks itself and relays rank 0's line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    env.update(RGCN_RCCL_LIBRARY=collective, RGCN_BENCH_SHARE_GPU="1")
+    env.update(RGCN_RCCL_LIBRARY=collective, RGCN_LIBRARY="devtools", RGCN_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
                         "--cpu-steps", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     check_multi_rank_line(r, world)

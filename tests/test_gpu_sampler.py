@@ -242,3 +242,36 @@ def test_thousands_of_components_against_the_host_sampler(native):
     for j in range(3):
         se = np.sqrt((dev[:, j].var() + ref[:, j].var()) / n) + 1e-9
         assert abs(dev[:, j].mean() - ref[:, j].mean()) <= 4.5 * se, (j, dev[:, j].mean(), ref[:, j].mean(), se)
+
+
+def test_draws_on_the_two_streams_do_not_share_a_draw(native):
+    """One set of per-draw state (parameters, distances, keys, the recorded graph) serves the main AND the prefetch
+    stream.  The driver's first iteration draws batch 1 on the main stream and at once batch 2 on the prefetch stream
+    (optimize.py: update_from_batch, then stage()): the second draw must wait for the first one's end instead of
+    overwriting the parameters its kernels still read.  Back-to-back draws on alternating streams give, bit for bit,
+    the batches the same seeds give one at a time (and never raise the batch-size flag)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_graph4", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    triples = bench.load_graph("synth:fb237_valid_test:272115")
+    V, k, rounds = 14541, 30000, 6
+    with native.Engine(V, 237, 4, 1, "block", 1, max_edges=k) as eng:
+        eng.neighborhood_reserve(triples)
+        bufs = [native.DeviceBuffer(eng, 12 * k) for _ in range(2 * rounds)]
+        try:
+            alone = []
+            for i in range(2 * rounds):
+                eng.sample_neighborhood_device(k, 1000 + i, bufs[0])
+                eng.sync()
+                alone.append(bufs[0].download(np.int32, (k, 3)))
+            for i in range(2 * rounds):          # no host wait between the draws; even: main stream, odd: prefetch stream
+                eng.sample_neighborhood_device(k, 1000 + i, bufs[i], on_prefetch_stream=bool(i % 2))
+            eng.sync()
+            for i in range(2 * rounds):
+                np.testing.assert_array_equal(bufs[i].download(np.int32, (k, 3)), alone[i], err_msg="draw %d" % i)
+        finally:
+            for b in bufs:
+                b.free()
