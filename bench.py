@@ -846,6 +846,8 @@ def measure_evaluation(args, queries=2000):
             lo, hi = np.searchsorted(ks, qkey, "left"), np.searchsorted(ks, qkey, "right")
             idx = np.concatenate([np.unique(vs[a:b]) for a, b in zip(lo, hi)]).astype(np.int32)
             ptr = np.concatenate([[0], np.cumsum([len(np.unique(vs[a:b])) for a, b in zip(lo, hi)])]).astype(np.int64)
+            if object_side:                 # steady state (a test set is tens of such calls): the first call of an engine
+                eng.ranks(q, object_side, ptr, idx)      # allocates its staging buffer and loads the kernels
             eng.sync()
             t0 = time.perf_counter()
             raw, filt = eng.ranks(q, object_side, ptr, idx)

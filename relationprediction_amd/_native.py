@@ -288,6 +288,9 @@ class Engine:
 
     def close(self):
         if self.ctx is not None:
+            if getattr(self, "_rank_buf", None) is not None:
+                self._rank_buf.free()
+                self._rank_buf = None
             self.lib.rgcn_destroy(self.ctx)
             self.ctx = None
 
@@ -493,15 +496,30 @@ class Engine:
         fp = np.ascontiguousarray(filter_ptr, dtype=np.int64)
         fi = np.ascontiguousarray(filter_idx, dtype=np.int32)
         assert fp.shape == (n + 1,) and fp[-1] == len(fi)
-        bufs = [self.to_device(x), self.to_device(fp), self.to_device(fi if len(fi) else np.zeros(1, np.int32)),
-                DeviceBuffer(self, 4 * n), DeviceBuffer(self, 4 * n)]
-        try:
-            self._check(self.lib.rgcn_rank_device(self.ctx, bufs[0].ptr, n, 1 if predict_object else 0, bufs[1].ptr,
-                                                  bufs[2].ptr, bufs[3].ptr, bufs[4].ptr))
-            return bufs[3].download(np.int32, (n,)), bufs[4].download(np.int32, (n,))
-        finally:
-            for b in bufs:
-                b.free()
+        # ONE upload (filter pointers | queries | filter list, packed) into a buffer the engine keeps, ONE download (raw |
+        # filtered ranks): a call used to cost five device allocations, three blocking uploads and two downloads --
+        # more host time than the scoring itself
+        nnz = max(len(fi), 1)
+        off_x, off_fi = 8 * (n + 1), 8 * (n + 1) + 12 * n
+        off_out = (off_fi + 4 * nnz + 7) // 8 * 8
+        total = off_out + 8 * n
+        if getattr(self, "_rank_buf", None) is None or self._rank_buf.nbytes < total:
+            if getattr(self, "_rank_buf", None) is not None:
+                self._rank_buf.free()
+            self._rank_buf = DeviceBuffer(self, max(total, 1 << 20))
+        host = np.zeros(off_out, dtype=np.uint8)
+        host[:off_x] = fp.view(np.uint8)
+        host[off_x:off_fi] = x.reshape(-1).view(np.uint8)
+        if len(fi):
+            host[off_fi:off_fi + 4 * len(fi)] = fi.view(np.uint8)
+        base = self._rank_buf.ptr.value if hasattr(self._rank_buf.ptr, "value") else int(self._rank_buf.ptr)
+        self._check(self.lib.rgcn_copy_to_device(self.ctx, C.c_void_p(base), _ptr(host), off_out))
+        self._check(self.lib.rgcn_rank_device(self.ctx, C.c_void_p(base + off_x), n, 1 if predict_object else 0,
+                                              C.c_void_p(base), C.c_void_p(base + off_fi), C.c_void_p(base + off_out),
+                                              C.c_void_p(base + off_out + 4 * n)))
+        out = np.empty(2 * n, dtype=np.int32)
+        self._check(self.lib.rgcn_copy_to_host(self.ctx, _ptr(out), C.c_void_p(base + off_out), 8 * n))
+        return out[:n].copy(), out[n:].copy()
 
     def optimizer_config(self, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0):
         self._check(self.lib.rgcn_optimizer_config(self.ctx, lr, beta1, beta2, eps, max_grad_norm))

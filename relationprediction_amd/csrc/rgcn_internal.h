@@ -400,6 +400,7 @@ struct rgcn_ctx {
   float* giant_slab = nullptr;           // [piece_cap][d] partial sums of giant-row pieces (scratch of one combine launch)
   float *rank_q = nullptr, *rank_s = nullptr;   // ranking: query rows [max,d], energies [max,V]
   int32_t* rank_bad = nullptr;
+  float* rank_thr = nullptr;             // per query: the smallest energy whose fp32 sigmoid reaches the gold entity's
   int64_t rank_max = 0;
   float* dcodes_own = nullptr;           // [V,d] staging for the host variant of backward
 
