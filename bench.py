@@ -343,6 +343,7 @@ def measure(workload, args, rk, steps, warmup, full):
         from relationprediction_amd.sharding import share_unique_id
         uid = share_unique_id(rank, rk.rdv_path, _native.Engine.comm_unique_id)
         eng.comm_init(uid)
+    rccl_ranks = eng.comm_info()[0] if world > 1 else None
     comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
 
     def allgather_scalar(x):
@@ -561,6 +562,10 @@ def measure(workload, args, rk, steps, warmup, full):
             "gpu_event_ms_per_step": round(gpu_ms / steps, 4),
             # collectives of one step on this rank (exclusive durations of the rccl_* launches; N = 1: none)
             "comm_ms_per_step": round(sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("rccl_")), 4),
+            # what the collective library itself says about the communicator (ncclCommCount): N ranks seen, or -1
+            "rccl_ranks": rccl_ranks,
+            "collectives": [[k["kernel"], k["launches_per_step"], k["avg_us"]] for k in kernels
+                            if k["kernel"].startswith("rccl_")],
             "message_edges_per_s": round(2 * L * value, 1),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,
@@ -907,7 +912,8 @@ def compact_line(out):
     Kept to a few KB (tests/test_gpu_multiprocess.py holds it under 8 KB); the tables live in bench_details.json."""
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data", "config")}
-    for k in ("gpu_event_ms_per_step", "comm_ms_per_step", "message_edges_per_s", "speedup_vs_cpu"):
+    for k in ("gpu_event_ms_per_step", "comm_ms_per_step", "rccl_ranks", "collectives", "message_edges_per_s",
+              "speedup_vs_cpu"):
         if k in out:
             line[k] = out[k]
     rf = out.get("roofline")

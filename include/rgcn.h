@@ -343,6 +343,11 @@ rgcn_status rgcn_comm_init(rgcn_ctx* ctx, const uint8_t id[128]);
 /* sum-all-reduce of `count` floats at a device pointer on the context's stream (used by bench.py
  * for its barrier / max-over-ranks reduction so that no second RCCL client is needed). */
 rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* ctx, float* dev, int64_t count);
+/* What the collective library itself reports about the context's communicator (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice): how many ranks it SEES, this rank's index, the device it is bound to -- the answer to "did RCCL
+ * come up with N ranks" from inside a run (bench.py prints it as "rccl_ranks").  -1 where there is no communicator
+ * (world == 1 / before rgcn_comm_init) or the bound library lacks the entry point. */
+rgcn_status rgcn_comm_info(rgcn_ctx* ctx, int32_t* comm_ranks, int32_t* comm_rank, int32_t* comm_device);
 
 /* Phase API: the same forward/backward cut at the points where a sharded run exchanges data.
  * rgcn_forward == begin; for l: partial(l) [all-reduce EXCHANGE] finish(l).

@@ -115,6 +115,7 @@ _SIGS = {
     "rgcn_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "rgcn_set_gemm_mode": (C.c_int32, [_P, C.c_int32]),
     "rgcn_set_fusion": (C.c_int32, [_P, C.c_int32]),
+    "rgcn_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_reset": (C.c_int32, [_P]),
     "rgcn_profile_count": (C.c_int32, [_P]),
@@ -602,6 +603,12 @@ class Engine:
     def comm_init(self, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self.lib.rgcn_comm_init(self.ctx, buf))
+
+    def comm_info(self):
+        """(ranks the collective library's communicator sees, this rank's index in it, its device); -1: unknown / none"""
+        n, r, dev = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        self._check(self.lib.rgcn_comm_info(self.ctx, C.byref(n), C.byref(r), C.byref(dev)))
+        return n.value, r.value, dev.value
 
     def comm_allreduce_sum(self, dev_buffer, count):
         self._check(self.lib.rgcn_comm_allreduce_sum(self.ctx, dev_buffer.ptr, int(count)))

@@ -29,6 +29,9 @@ struct Rccl {
   int (*ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(nccl_comm_t, int*) = nullptr;        // optional (rgcn_comm_info)
+  int (*CommUserRank)(nccl_comm_t, int*) = nullptr;
+  int (*CommCuDevice)(nccl_comm_t, int*) = nullptr;
   std::string error;
 };
 
@@ -67,6 +70,9 @@ bool load_rccl(std::string* err) {
   r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(r.handle, "ncclReduceScatter");
   r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+  r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
+  r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.handle, "ncclCommUserRank");
+  r.CommCuDevice = (decltype(r.CommCuDevice))dlsym(r.handle, "ncclCommCuDevice");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.ReduceScatter || !r.AllGather ||
       !r.GetErrorString) {
     *err = "librccl.so.1 lacks an expected nccl* symbol";
@@ -139,6 +145,19 @@ rgcn_status comm_all_gather(rgcn_ctx* c, float* buf, int64_t count) {
   int rc = rccl().AllGather(buf + (size_t)c->rank * count, buf, (size_t)count, kNcclFloat32, (nccl_comm_t)c->comm,
                             c->stream);
   if (rc != 0) RGCN_FAIL(c, RGCN_ERR_RCCL, nccl_err("ncclAllGather", rc));
+  return RGCN_OK;
+}
+
+rgcn_status comm_info(rgcn_ctx* c, int32_t* ranks, int32_t* rank, int32_t* device) {
+  int n = -1, r = -1, dev = -1;
+  if (c->comm) {
+    if (rccl().CommCount && rccl().CommCount((nccl_comm_t)c->comm, &n) != 0) n = -1;
+    if (rccl().CommUserRank && rccl().CommUserRank((nccl_comm_t)c->comm, &r) != 0) r = -1;
+    if (rccl().CommCuDevice && rccl().CommCuDevice((nccl_comm_t)c->comm, &dev) != 0) dev = -1;
+  }
+  if (ranks) *ranks = n;
+  if (rank) *rank = r;
+  if (device) *device = dev;
   return RGCN_OK;
 }
 

@@ -1470,6 +1470,11 @@ rgcn_status rgcn_comm_init(rgcn_ctx* c, const uint8_t id[128]) {
   if (!id) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL id");
   return comm_init(c, id);
 }
+rgcn_status rgcn_comm_info(rgcn_ctx* c, int32_t* comm_ranks, int32_t* comm_rank, int32_t* comm_device) {
+  RGCN_NEED(c);
+  return comm_info(c, comm_ranks, comm_rank, comm_device);
+}
+
 rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* c, float* dev, int64_t count) {
   RGCN_NEED(c);
   return comm_allreduce(c, dev, count);

@@ -573,6 +573,7 @@ rgcn_status comm_init(rgcn_ctx* c, const uint8_t id[128]);
 rgcn_status comm_allreduce(rgcn_ctx* c, float* buf, int64_t count);
 rgcn_status comm_reduce_scatter(rgcn_ctx* c, float* buf, int64_t count_per_rank);
 rgcn_status comm_all_gather(rgcn_ctx* c, float* buf, int64_t count_per_rank);
+rgcn_status comm_info(rgcn_ctx* c, int32_t* ranks, int32_t* rank, int32_t* device);
 void comm_destroy(rgcn_ctx* c);
 
 }  // namespace rgcn

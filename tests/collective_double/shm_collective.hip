@@ -64,6 +64,9 @@ int ncclGetUniqueId(ncclUniqueId* id) {
   return 0;
 }
 
+int ncclCommCount(void* comm, int* count) { *count = static_cast<Comm*>(comm)->nranks; return 0; }
+int ncclCommUserRank(void* comm, int* rank) { *rank = static_cast<Comm*>(comm)->rank; return 0; }
+
 int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank) {
   Comm* c = new Comm();
   c->rank = rank;

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / at round end)")
+    config.addinivalue_line("markers", "slow: tens of seconds on the GPU box (large-sample statistics)")
 
 
 def _has_gpu():

@@ -69,6 +69,8 @@ def check_multi_rank_line(r, world):
     assert out["n_gpus"] == world and out["steps"] == 4 and out["value"] > 0
     assert out["config"]["parallelism"].startswith("relation-sharded x%d" % world)
     assert out["roofline"] and out["comm_ms_per_step"] > 0
+    # what the collective library itself reports (ncclCommCount), and the collectives of one step by name
+    assert out["rccl_ranks"] == world and {c[0] for c in out["collectives"]} >= {"rccl_reduce_scatter", "rccl_all_gather"}
     with open(os.path.join(ROOT, out["details"])) as f:          # the per-kernel tables live in the side file
         names = {k["kernel"] for k in json.load(f)["kernels"]}
     assert {"rccl_allreduce", "rccl_reduce_scatter", "rccl_all_gather"} <= names
