@@ -158,7 +158,24 @@ KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "
                  "prep_keys": "k_keys", "prep_ptrs": "k_ptrs", "prep_build_msgs": "k_build_msgs",
                  "gemm_basis_fwd": "k_gemm_bf16x3<true, false", "gemm_basis_dz": "k_gemm_bf16x3<true, true",
                  "gemm_basis_dw": "k_gemm_bf16x3<false, false", "basis_agg": "k_basis_agg",
-                 "basis_bwd_gather": "k_basis_bwd_gather", "basis_dcoef": "k_basis_dcoef"}
+                 "basis_bwd_gather": "k_basis_bwd_gather", "basis_dcoef": "k_basis_dcoef",
+                 # (prefix, substring): template arguments in the middle of the name tell the instantiations apart
+                 "block_rows_fwd": ("k_block_rows<", ", false,"), "block_rows_bwd": ("k_block_rows<", ", true,"),
+                 "block_dw_msgs": ("k_block_msg_bwd<", ", false>"), "prep_row_order": "k_sort_hist",
+                 "block_wtile_build": "k_wtile_build"}
+
+
+def kernel_traffic(traffic, tag, args):
+    """bytes per launch of the kernel behind a profile tag in a {HIP kernel name: bytes} table (None: not there)"""
+    pref = KERNEL_OF_TAG.get(tag)
+    if not pref:
+        return None
+    pref, sub = pref if isinstance(pref, tuple) else (pref, "")
+    if tag == "block_msg_bwd":
+        sub = ", true>"
+    if pref.startswith("k_gemm") and args.gemm_mode == 0:
+        return None                   # the PMC passes ran the default arithmetic
+    return next((round(v) for n, v in traffic.items() if n.startswith(pref) and sub in n), None)
 
 
 def traffic_table(workload):
@@ -245,10 +262,7 @@ def apply_live_traffic(out, args):
         return
     traffic, src = LIVE_TRAFFIC[out["config"]["workload"]]
     for k in out["kernels"]:
-        pref = KERNEL_OF_TAG.get(k["kernel"])
-        if pref and pref.startswith("k_gemm") and args.gemm_mode == 0:
-            pref = None
-        k["traffic"] = next((round(v) for n, v in traffic.items() if pref and n.startswith(pref)), None)
+        k["traffic"] = kernel_traffic(traffic, k["kernel"], args)
     if out.get("roofline"):
         top = next((k for k in out["kernels"] if k["kernel"] == out["roofline"]["kernel"]), None)
         if top is not None:
@@ -451,10 +465,7 @@ def measure(workload, args, rk, steps, warmup, full):
         kernels = kernel_table(prof, steps, args, in_pipeline)
         traffic, traffic_src = traffic_table(workload)
         for k in kernels:
-            pref = KERNEL_OF_TAG.get(k["kernel"])
-            if pref and pref.startswith("k_gemm") and args.gemm_mode == 0:
-                pref = None          # the PMC passes ran the default arithmetic
-            k["traffic"] = next((round(v) for n, v in traffic.items() if pref and n.startswith(pref)), None)
+            k["traffic"] = kernel_traffic(traffic, k["kernel"], args)
         kernels.sort(key=lambda k: -k["ms_per_step"])
         if kernels:
             k = kernels[0]
