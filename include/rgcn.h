@@ -399,7 +399,8 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
  *   1 : as 0, with the reduce as the epilogue of the self-loop GEMM (the product never travels; measured slower)
  *   2 : round 3's single pass (csrc/block_spmm.hip): per-block workgroups, LDS-resident weight table (needs 2R x sd^2
  *       floats of LDS), 20-byte gathers; 2.4x slower than form 0 at minibatch scale, 3.7x at 272 k edges.
- * Other kinds and sharded contexts run form 0 whatever the setting. */
+ * The basis kind runs its own kernels whatever the setting; on relation-sharded contexts (world > 1) form 3 walks the
+ * rank's own messages and writes the partial pre-activations for the exchange (since round 4), forms 1 / 2 fall back to 0. */
 rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t mode);
 
 /* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.

@@ -532,7 +532,7 @@ hipError_t launch_rows_gw(rgcn_ctx* c, const RowsArgs& a, bool backward, int gri
 
 
 bool block_rows_available(const rgcn_ctx* c) {
-  return c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->nb <= 512 && c->g.d_src != nullptr && c->g.row_order != nullptr;
+  return c->kind == RGCN_KIND_BLOCK && c->nb <= 512 && c->g.d_src != nullptr && c->g.row_order != nullptr;
 }
 
 // band-tiled copy of a layer's relation weights, rebuilt when the weights changed (set_param, Adam) -- and inside every

@@ -472,7 +472,7 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
   RGCN_TRY(dalloc(c, &g.m_dslot, M));
   RGCN_TRY(dalloc(c, &g.m_sslot, M));
   RGCN_TRY(dalloc(c, &g.m_norm, M));
-  if (c->kind == RGCN_KIND_BASIS || c->world == 1) {      // slot-ordered message lists (row-major gathers)
+  {      // slot-ordered message lists (row-major gathers): the basis kind and the destination-major block layer
     RGCN_TRY(dalloc(c, &g.d_src, M));
     RGCN_TRY(dalloc(c, &g.d_rel, M));
     RGCN_TRY(dalloc(c, &g.d_norm, M));
@@ -480,7 +480,7 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
     RGCN_TRY(dalloc(c, &g.s_rel, M));
     RGCN_TRY(dalloc(c, &g.s_norm, M));
   }
-  if (c->kind == RGCN_KIND_BLOCK && c->world == 1) {
+  if (c->kind == RGCN_KIND_BLOCK) {
     RGCN_TRY(dalloc(c, &g.row_key, V));
     RGCN_TRY(dalloc(c, &g.row_key_s, V));
     RGCN_TRY(dalloc(c, &g.row_order, V));

@@ -547,7 +547,7 @@ static bool fused_layer(const rgcn_ctx* c) {
 // The block layer as ONE pass over the incidence CSR (block_spmm.hip): block kind, one GPU, weight table in LDS.
 static bool spmm_layer(const rgcn_ctx* c) { return c->fuse == 2 && block_spmm_available(c); }
 // ... destination-major, one column band per XCD, weights through L2 (block_rows.hip): block kind, one GPU.
-static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 3 && block_rows_available(c); }
+static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 3 && block_rows_available(c); }   // (any world)
 static rgcn_status single_pass(rgcn_ctx* c, const char* tag, int l, bool backward, const float* X, const CombineArgs& a) {
   return rows_layer(c) ? block_rows(c, tag, l, backward, X, a) : block_spmm(c, tag, l, backward, X, a);
 }
@@ -562,12 +562,17 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (spmm_layer(c) || rows_layer(c)) {
     // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
     // the incidence CSR (no message buffer)
-    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, V, d, d, Hin, d, c->layers[l].wself, d, c->self_buf, d, 1));
+    // (sharded run, form 3 only: the self-loop GEMM covers this rank's row shard, the kernel walks the rank's own
+    // messages and writes the PARTIAL pre-activations -- the self-loop term inside the shard only, no relu -- for the
+    // reduce-scatter that follows)
+    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d, c->layers[l].wself, d,
+                      c->self_buf + (size_t)lo * d, d, 1));
+    RGCN_TRY(wait_gather(c));
     CombineArgs a;
     a.add = nullptr; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.gate = nullptr; a.V = V; a.d = d;
-    a.relu = l < c->L ? 1 : 0;
-    a.row_lo = 0; a.row_hi = V;
+    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
+    a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
     a.drop2 = make_drop(c, l, false);
     RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_fwd" : "block_spmm_fwd", l, false, Hin, a));
@@ -703,16 +708,19 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // stream 0 beside the self-loop GEMMs; the row gradients come from the single-pass kernel behind G = dS . W_self^T
     {
       StreamScope side(c, 0);
+      RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
       RGCN_TRY(block_dw_reduce(c, l));
       c->dw_pending = side.active;
     }
-    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, V, d, d, c->bwd_dS, d, lb.wself, d, c->self_buf, d, 1));
+    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                      c->self_buf + (size_t)lo * d, d, 1));
     {
       StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, V, Hin, d, c->bwd_dS, d, lb.gwself, d,
-                        auto_split_k(d, d, V)));
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                        lb.gwself, d, auto_split_k(d, d, rows)));
     }
+    RGCN_TRY(wait_gather(c));
     RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
   } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
