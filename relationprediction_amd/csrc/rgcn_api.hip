@@ -51,12 +51,17 @@ StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), act
   if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess) return;
   if (hipStreamWaitEvent(c->aux[k], c->ev_fork, 0) != hipSuccess) return;
   c->stream = c->aux[k];
+  c->aux_dirty[k] = true;
   active = true;
 }
 StreamScope::~StreamScope() { c->stream = saved; }
 
 rgcn_status stream_join(rgcn_ctx* c, int k) {
   if (!c->use_aux || c->stream != c->main_stream) return RGCN_OK;   // nothing was forked
+  // a join costs the main stream ~3.6 us even when the side stream is idle (tools/anyorder_probe.hip): skip it when
+  // nothing went to that stream since its last join
+  if (!c->aux_dirty[k]) return RGCN_OK;
+  c->aux_dirty[k] = false;
   RGCN_HIP(c, hipEventRecord(c->ev_join[k], c->aux[k]));
   RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[k], 0));
   return RGCN_OK;
@@ -706,6 +711,14 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   if (spmm_layer(c) || rows_layer(c)) {
     // weight gradients of the relations (dW_r = sum n g (x) x, relation-major, two row gathers per message) on side
     // stream 0 beside the self-loop GEMMs; the row gradients come from the single-pass kernel behind G = dS . W_self^T
+    // One GPU: everything of the layer on the main stream.  The row-gradient kernel needs the dH GEMM's product, so the
+    // layer's chain has nothing to overlap with, and the two independent kernels (relation-weight gradients, dW_self)
+    // beside it only stretch it: 0.589-0.599 ms per step serial against 0.595-0.610 with them on side streams
+    // (tools/gpu_sched_ab.sh, three boxes).  Sharded runs keep the side streams (the all-gather rides on one).
+    static const int rows_serial_env = getenv("RGCN_ROWS_SERIAL") ? atoi(getenv("RGCN_ROWS_SERIAL")) : 1;
+    const bool serial = rows_serial_env != 0 && c->world == 1;
+    const bool aux_saved = c->use_aux;
+    if (serial) c->use_aux = false;
     {
       StreamScope side(c, 0);
       RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
@@ -720,6 +733,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                         lb.gwself, d, auto_split_k(d, d, rows)));
     }
+    c->use_aux = aux_saved;
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
   } else if (fused_layer(c)) {
@@ -1194,6 +1208,7 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
   if (c->use_aux || fork_in_capture) {
     RGCN_HIP(c, hipStreamWaitEvent(c->aux[1], c->ev_step_begin, 0));
     c->stream = c->aux[1];
+    c->aux_dirty[1] = true;
     const rgcn_status ps = decoder_prepare(c, X_loc, n_loc, N);
     c->stream = c->main_stream;
     RGCN_TRY(ps);

@@ -327,6 +327,7 @@ struct rgcn_ctx {
                                                                // 2 for the decoder's relation gradient (runs beside the backward pass)
   hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
+  bool aux_dirty[rgcn::kAuxStreams] = {false, false, false};   // something was forked onto side stream k since its last join
   // block kind, one GPU: 0 = message kernel + k_combine (two kernels, [2E,d] message buffer), 1 = self-loop GEMM with
   // the combine as its epilogue, 2 = single-pass block SpMM (block_spmm.hip; no message buffer at all), 3 = the
   // destination-major banded single-pass layer (block_rows.hip; no message buffer, weights through L2)
