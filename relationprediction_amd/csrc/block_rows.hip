@@ -531,6 +531,11 @@ hipError_t launch_rows_gw(rgcn_ctx* c, const RowsArgs& a, bool backward, int gri
 }  // namespace
 
 
+// floats of one layer's band-tiled weight copy (allocated at create: a capture may be the first call that needs it)
+size_t block_rows_weight_floats(const rgcn_ctx* c) {
+  return (size_t)2 * c->R * 8 * nt_of(c->sd) * rows_group_width(c) * 4;
+}
+
 bool block_rows_available(const rgcn_ctx* c) {
   return c->kind == RGCN_KIND_BLOCK && c->nb <= 512 && c->g.d_src != nullptr && c->g.row_order != nullptr;
 }
@@ -541,7 +546,10 @@ static rgcn_status block_rows_refresh_weights(rgcn_ctx* c, int layer) {
   LayerBufs& lb = c->layers[layer];
   const int gw = rows_group_width(c), nt = nt_of(c->sd);
   const int64_t n4 = (int64_t)2 * c->R * 8 * nt * gw;
-  if (!lb.wtile) RGCN_HIP(c, hipMalloc((void**)&lb.wtile, sizeof(float) * 4 * (size_t)n4));
+  if (!lb.wtile) {
+    if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: the band-tiled weight copy must exist before a capture");
+    RGCN_HIP(c, hipMalloc((void**)&lb.wtile, sizeof(float) * 4 * (size_t)n4));
+  }
   if (!c->capturing && lb.wtile_version == c->weights_version) return RGCN_OK;
   ProfScope ps(c, "block_wtile_build", 4.0 * (2.0 * c->R * c->sd * c->sd * c->nb) + 16.0 * n4, 0);
   hipLaunchKernelGGL(k_wtile_build, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, lb.wrel, lb.wtile,

@@ -412,6 +412,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
       add_param(c, "W_f" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel, lb.grel, LAYOUT_BLOCK_T);
       add_param(c, "W_b" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel + per_dir, lb.grel + per_dir, LAYOUT_BLOCK_T);
       if (block_spmm_available(c)) RGCN_TRY(dmalloc(c, &lb.wbm, block_spmm_weight_floats(c)));
+      if (c->nb <= 512) RGCN_TRY(dmalloc(c, &lb.wtile, block_rows_weight_floats(c)));
     } else {
       const size_t per_dir = (size_t)c->B * d * d;
       RGCN_TRY(dmalloc(c, &lb.wrel, 2 * per_dir));

@@ -494,6 +494,7 @@ rgcn_status block_spmm(rgcn_ctx* c, const char* tag, int layer, bool backward, c
 // ---- block_rows.hip: the block layer destination-major in ONE pass per direction, one column band per XCD, weights
 // through L2 (no LDS table, no message buffer); bitwise equal to the two-kernel form
 bool block_rows_available(const rgcn_ctx* c);
+size_t block_rows_weight_floats(const rgcn_ctx* c);
 rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca);
 
 // ---- basis.hip
