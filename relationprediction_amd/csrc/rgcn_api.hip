@@ -727,12 +727,27 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(block_dw_reduce(c, l));
       c->dw_pending = side.active;
     }
+    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
+    if (corun_env && aux_saved && c->world == 1) {
+      // the two self-loop gradient GEMMs SIDE BY SIDE (dW_self forked before dH is launched): the second fills the CU
+      // slots the first leaves idle (456 workgroups on 512) and its tail -- 0.588-0.592 ms per step against 0.597-0.599
+      // with one behind the other (tools/gpu_corun_ab.sh), the one cross-stream join included
+      c->use_aux = true;
+      {
+        StreamScope side(c, 1);
+        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                          lb.gwself, d, auto_split_k(d, d, rows)));
+      }
+      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                        c->self_buf + (size_t)lo * d, d, 1));
+    } else {
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                       c->self_buf + (size_t)lo * d, d, 1));
     {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                         lb.gwself, d, auto_split_k(d, d, rows)));
+    }
     }
     c->use_aux = aux_saved;
     RGCN_TRY(wait_gather(c));
