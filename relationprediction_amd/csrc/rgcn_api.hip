@@ -47,7 +47,7 @@ ProfScope::~ProfScope() {
 }
 
 StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), active(false) {
-  if (!c->use_aux || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
+  if (k < 0 || !c->use_aux || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
   if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess) return;
   if (hipStreamWaitEvent(c->aux[k], c->ev_fork, 0) != hipSuccess) return;
   c->stream = c->aux[k];
@@ -633,12 +633,19 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   } else {
     // aggregate first: Z[v,(dir,b),:] = sum n C[rel,b] H[src];  pre = dropout(H.W_self) + Z.W'
     const int zc = 2 * c->B * d;
+    // the self-loop GEMM needs the layer input only: it runs on side stream 1 beside the aggregation (HBM-bound) and
+    // then beside the basis GEMM, whose last round of tiles leaves CUs idle (RGCN_GEMM_CORUN, as in the backward pass)
+    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
+    {
+      StreamScope side(c, corun_env ? 1 : -1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
+                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+    }
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
-    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                      c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, zc, c->zsave[l], zc, c->layers[l].wrel, d,
                       c->aggbuf, d, 1));
+    RGCN_TRY(stream_join(c, 1));
     CombineArgs a;
     a.add = c->aggbuf;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr;
@@ -809,16 +816,25 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
                         c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
   } else {
     const int zc = 2 * c->B * d;
-    // self-loop gradients
-    RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                      c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+    // The four dense contractions of the layer depend on D_l / dS_l only.  Two of them -- the weight gradients dW_self =
+    // H^T.dS and dW' = Z^T.D, needed at the end of the pass -- go to side stream 1, the two whose products the gather
+    // kernels below consume (dH's self-loop part, dZ) stay on the main stream: the pairs fill each other's idle CU slots
+    // and tails (RGCN_GEMM_CORUN=0: all four one behind the other).
+    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
+    {
+      StreamScope side(c, corun_env ? 1 : -1);
+      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+      // dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
+      RGCN_TRY(wait_gather(c));            // D_l of every row
+      RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
+                        auto_split_k(zc, d, V)));
+    }
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                       c->self_buf + (size_t)lo * d, d, 1));
-    // dZ = D . W'^T   ([V,d] x [d,2B.d]);   dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
+    // dZ = D . W'^T   ([V,d] x [d,2B.d])
     RGCN_TRY(wait_gather(c));            // D_l of every row
     RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, zc, d, c->bwd_D, d, lb.wrel, d, c->msgbuf2, zc, 1));
-    RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
-                      auto_split_k(zc, d, V)));
     RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
     RGCN_TRY(basis_backward_gather(c, l, c->msgbuf2, a, true));
   }
