@@ -724,37 +724,42 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // beside it only stretch it: 0.589-0.599 ms per step serial against 0.595-0.610 with them on side streams
     // (tools/gpu_sched_ab.sh, three boxes).  Sharded runs keep the side streams (the all-gather rides on one).
     static const int rows_serial_env = getenv("RGCN_ROWS_SERIAL") ? atoi(getenv("RGCN_ROWS_SERIAL")) : 1;
+    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
     const bool serial = rows_serial_env != 0 && c->world == 1;
     const bool aux_saved = c->use_aux;
+    const bool corun = corun_env != 0 && aux_saved && c->world == 1;
     if (serial) c->use_aux = false;
     {
       StreamScope side(c, 0);
       RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-      RGCN_TRY(block_dw_reduce(c, l));
+      if (!corun) RGCN_TRY(block_dw_reduce(c, l));
       c->dw_pending = side.active;
     }
-    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
-    if (corun_env && aux_saved && c->world == 1) {
-      // the two self-loop gradient GEMMs SIDE BY SIDE (dW_self forked before dH is launched): the second fills the CU
-      // slots the first leaves idle (456 workgroups on 512) and its tail -- 0.588-0.592 ms per step against 0.597-0.599
-      // with one behind the other (tools/gpu_corun_ab.sh), the one cross-stream join included
+    if (corun) {
+      // MFMA beside MFMA is the pairing that pays: dW_self = H^T.dS is forked to side stream 1 BEFORE dH = dS.W^T is
+      // launched, so the second GEMM fills the CU slots the first leaves idle (456 workgroups on 512) and its tail; the
+      // slab reduce of the relation-weight gradients (small, latency-bound) leads that side stream and runs under the
+      // dH GEMM's start.  0.566-0.574 ms per step against 0.580-0.587 with only the GEMMs paired and 0.597-0.599 with
+      // everything one behind the other (tools/gpu_corun_ab.sh); the message-gradient kernel itself beside the GEMMs
+      // (either end of the side stream) loses 8-10 us again.
       c->use_aux = true;
       {
         StreamScope side(c, 1);
+        RGCN_TRY(block_dw_reduce(c, l));
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                           lb.gwself, d, auto_split_k(d, d, rows)));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                         c->self_buf + (size_t)lo * d, d, 1));
     } else {
-    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                      c->self_buf + (size_t)lo * d, d, 1));
-    {
-      StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                        lb.gwself, d, auto_split_k(d, d, rows)));
-    }
+      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                        c->self_buf + (size_t)lo * d, d, 1));
+      {
+        StreamScope side(c, 1);
+        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                          lb.gwself, d, auto_split_k(d, d, rows)));
+      }
     }
     c->use_aux = aux_saved;
     RGCN_TRY(wait_gather(c));
