@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
                                                    int n_rel, int rel_scale, int32_t* row_ptr, int32_t* long_rows, int32_t* nlong, int cap,
                                                    int32_t* long_first, int32_t* long_cnt, int32_t* piece_row,
                                                    int32_t* piece_k, int piece_cap, int32_t* rel_ptr,
-                                                   int32_t* chunk_ptr) {
+                                                   int32_t* chunk_ptr, uint32_t* row_key) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
   row_ptr[v] = beg;
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, 2 * N, (uint32_t)(v + 1));
+  // sort key of the line form's row order: descending length (long rows, which it skips, in front)
+  row_key[v] = end - beg > kDecLongRow ? 0u : (uint32_t)(255 - min(end - beg, 255));
   if (end - beg > kDecLongRow) {
     // pieces of one row get consecutive ids, so the finishing pass adds them in a fixed order whatever
     // order the rows were registered in
@@ -424,6 +426,165 @@ __global__ void __launch_bounds__(256) k_dec_long_finish(EntArgs a) {
   }
 }
 
+// ---- K2, line form (round 4) -----------------------------------------------------------------------
+// The kernel above gathers one 2 KB partner row per incidence: 660,000 rows at N = 330,000, 1.28 GB through the
+// L2 <-> fabric interface, because the 29 MB code table fits no L2 (8 XCDs x 4 MB).  Every element of dL/dcodes is its
+// own sum over the row's incidences, so the columns can be taken band by band: here a band is 32 floats = ONE 128-byte
+// line of a band-major, line-aligned COPY of the table (`cb [bands][V][32]`, built per call by k_dec_band_tables, 12 us)
+// -- 1.86 MB per band at FB15k-237 size.  The workgroups with blockIdx % 8 == x (one XCD) take band x of every row,
+// then band x + 8: the band lives in that XCD's L2 while its 660,000 line gathers go by.  (Round 4's first attempt banded the
+// ROW-MAJOR table: 250-byte pieces = three lines each, a 5.6 MB footprint per XCD, and lost to the full-row kernel.)
+// Eight lanes (float4 each) own a (row, band); a wavefront takes eight rows per turn, each group walking its row's
+// incidences one after the other in k_dec_entity_grad's own order and arithmetic -- every sum is that kernel's, bit for
+// bit; pieces of long rows: eight interleaved slot groups, their partial sums added in group order, as there.  The band
+// of W_relation ([R][32], 30 KB at R = 237) sits in LDS when it fits.
+constexpr int kLine = 32;                 // floats per (row, band)
+constexpr int kLineTurns = 4;             // turns of eight rows per wavefront
+constexpr int kLineRows = 4 * kLineTurns * 8;   // rows per workgroup
+
+struct LineArgs {
+  const float* cb;          // [bands][V][32]
+  const float* rb;          // [bands][R][32]
+  const float* e_g;         // loss gradient of every incidence slot
+  const int32_t* row_order; // rows by descending number of incidences
+  int32_t R, nbands, nlb, nchunks;
+};
+
+__global__ void __launch_bounds__(256) k_dec_band_tables(const float* __restrict__ codes, const float* __restrict__ Wr,
+                                                         int V, int R, int d, int nbands, float* __restrict__ cb,
+                                                         float* __restrict__ rb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per = nbands * (kLine / 4);
+  const int64_t row = i / per;
+  const int q = (int)(i - row * per);
+  if (row >= (int64_t)V + R) return;
+  const bool ent = row < V;
+  const int64_t r = ent ? row : row - V;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (4 * q < d) v = *reinterpret_cast<const float4*>((ent ? codes : Wr) + r * d + 4 * q);
+  float* dst = ent ? cb + ((int64_t)(q >> 3) * V + r) * kLine : rb + ((int64_t)(q >> 3) * R + r) * kLine;
+  *reinterpret_cast<float4*>(dst + (q & 7) * 4) = v;
+}
+
+// One group's sum over the incidences s0, s0 + step, s0 + 2 step, ... < s1, in that order (ent_range's terms and
+// order).  The group's eight lanes fetch the (partner, relation, loss gradient) of eight incidences with one load each
+// -- lane cl the (base + cl)-th of the sequence -- and hand them round by ds_bpermute; the next eight are requested
+// before this block's lines are waited for, so the chain per block is ONE memory level (the lines), not three.
+// Lanes past the end of the sequence hold partner 0 / relation 0 / gradient 0: a valid line and a term g u w = +-0,
+// which leaves the accumulator as it is, bit for bit (it never holds -0: it starts at +0) -- no branch per incidence.
+// Byte offsets are 32-bit (a band of the table is V x 128 bytes) on a uniform base: one VALU add per address.
+template <bool RLDS>
+__device__ __forceinline__ void line_range(const EntArgs& a, const float* __restrict__ e_g, const char* __restrict__ cbb,
+                                           const char* __restrict__ rbb, const char* rl, int s0, int s1, int step,
+                                           int g, int cl, float (&acc)[4]) {
+  const int n = s1 > s0 ? (s1 - s0 + step - 1) / step : 0;
+  uint32_t oth = 0, rel = 0;
+  float gg = 0.f;
+  if (cl < n) {
+    const int s = s0 + cl * step;
+    oth = (uint32_t)a.e_other[s] * (kLine * 4); rel = (uint32_t)a.e_rel[s] * (kLine * 4); gg = e_g[s];
+  }
+  const uint32_t cb16 = (uint32_t)cl * 16;
+  for (int base = 0; base < n; base += 8) {
+    const uint32_t co = oth, cr = rel;
+    const float cg = gg;
+    float4 u[8], w[8];
+    float gt[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t ot = __shfl(co, g * 8 + t, 64), rt = __shfl(cr, g * 8 + t, 64);
+      gt[t] = __shfl(cg, g * 8 + t, 64);
+      u[t] = *reinterpret_cast<const float4*>(cbb + (ot + cb16));
+      if constexpr (RLDS) w[t] = *reinterpret_cast<const float4*>(rl + (rt + cb16));
+      else w[t] = *reinterpret_cast<const float4*>(rbb + (rt + cb16));
+    }
+    oth = 0; rel = 0; gg = 0.f;
+    if (base + 8 + cl < n) {
+      const int s = s0 + (base + 8 + cl) * step;
+      oth = (uint32_t)a.e_other[s] * (kLine * 4); rel = (uint32_t)a.e_rel[s] * (kLine * 4); gg = e_g[s];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc[0] = fmaf(gt[t] * u[t].x, w[t].x, acc[0]);
+      acc[1] = fmaf(gt[t] * u[t].y, w[t].y, acc[1]);
+      acc[2] = fmaf(gt[t] * u[t].z, w[t].z, acc[2]);
+      acc[3] = fmaf(gt[t] * u[t].w, w[t].w, acc[3]);
+    }
+  }
+}
+
+// e_g[slot] = dx[triple of the slot]: the loss gradients in the order of the by-entity incidence lists
+__global__ void k_dec_slot_grad(const int32_t* __restrict__ e_trip, const float* __restrict__ dx,
+                                const int32_t* __restrict__ row_ptr, int V, float* __restrict__ e_g) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < row_ptr[V]) e_g[s] = dx[e_trip[s]];
+}
+
+template <bool RLDS>
+__global__ void __launch_bounds__(256) k_dec_entity_lines(EntArgs a, LineArgs b) {
+  extern __shared__ float rl[];                       // RLDS: this band of W_relation, [R][32]
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int per = b.nlb + b.nchunks;
+  const int band = (j / per) * 8 + x, within = j % per;
+  if (band >= b.nbands) return;
+  const char* __restrict__ cbb = reinterpret_cast<const char*>(b.cb + (size_t)band * a.V * kLine);
+  const char* __restrict__ rbb = reinterpret_cast<const char*>(b.rb + (size_t)band * b.R * kLine);
+  if constexpr (RLDS) {
+    for (int i = threadIdx.x; i < b.R * (kLine / 4); i += 256)
+      reinterpret_cast<float4*>(rl)[i] = reinterpret_cast<const float4*>(rbb)[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, cl = lane & 7;
+  const int col = band * kLine + cl * 4;
+  const bool colok = col < a.d;                       // d % 4 == 0: the whole float4 is inside the row, or none of it
+  if (within < b.nlb) {
+    // pieces of long rows: one piece per wavefront and turn, eight interleaved slot groups
+    const int n = a.nlong[1];
+    for (int lb = within * 4 + wave; lb < n; lb += b.nlb * 4) {
+      const int v = a.piece_row[lb];
+      const int beg = a.row_ptr[v] + a.piece_k[lb] * kDecPiece;
+      const int end = min(a.row_ptr[v + 1], beg + kDecPiece);
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      line_range<RLDS>(a, b.e_g, cbb, rbb, reinterpret_cast<const char*>(rl), beg + g, end, 8, g, cl, part);
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t[k] = __shfl(part[k], cl, 64);
+#pragma unroll
+        for (int p = 1; p < 8; ++p) t[k] += __shfl(part[k], p * 8 + cl, 64);
+      }
+      if (g == 0 && colok) vstore<4>(a.piece_slab + (size_t)lb * a.d + col, t);
+    }
+    return;
+  }
+  // short rows in the order of descending length (b.row_order), eight per turn; turn t of wavefront w is the
+  // (t W + w)-th group of eight, W = the band's wavefronts: every wavefront gets long turns and short ones
+  const int W = b.nchunks * 4, wid = (within - b.nlb) * 4 + wave;
+  int vs[kLineTurns], beg[kLineTurns], end[kLineTurns];
+#pragma unroll
+  for (int t = 0; t < kLineTurns; ++t) {
+    const int slot = (t * W + wid) * 8 + g;
+    vs[t] = -1; beg[t] = end[t] = 0;
+    if (slot < a.V) {
+      vs[t] = b.row_order[slot];
+      beg[t] = a.row_ptr[vs[t]]; end[t] = a.row_ptr[vs[t] + 1];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kLineTurns; ++t) {
+    if (vs[t] < 0 || end[t] - beg[t] > kDecLongRow) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    line_range<RLDS>(a, b.e_g, cbb, rbb, reinterpret_cast<const char*>(rl), beg[t], end[t], 1, g, cl, acc);
+    const float4 self = *reinterpret_cast<const float4*>(cbb + ((size_t)vs[t] * kLine + cl * 4) * sizeof(float));
+    const float kc = a.k * (float)(end[t] - beg[t]);
+    acc[0] = fmaf(kc, self.x, acc[0]);
+    acc[1] = fmaf(kc, self.y, acc[1]);
+    acc[2] = fmaf(kc, self.z, acc[2]);
+    acc[3] = fmaf(kc, self.w, acc[3]);
+    if (colok) store_dcodes<4>(a, (size_t)vs[t] * a.d + col, acc);
+  }
+}
+
 // ---- K3: relation gradients ------------------------------------------------------------------------
 __device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int n_seg, int x) {
   int lo = 0, hi = n_seg;
@@ -701,6 +862,12 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.piece_slab, (size_t)q.piece_cap * d));
   RGCN_TRY(dalloc(c, &q.nlong, 2));
   RGCN_TRY(dalloc(c, &q.dx, N));
+  q.nbands = (int32_t)((d + kLine - 1) / kLine);
+  RGCN_TRY(dalloc(c, &q.cb, (size_t)q.nbands * V * kLine));
+  RGCN_TRY(dalloc(c, &q.rb, (size_t)q.nbands * R * kLine));
+  RGCN_TRY(dalloc(c, &q.e_g, 2 * N));
+  RGCN_TRY(dalloc(c, &q.row_key, V)); RGCN_TRY(dalloc(c, &q.row_key_s, V)); RGCN_TRY(dalloc(c, &q.row_order, V));
+  RGCN_TRY(dalloc(c, &q.row_tab, sort_table_elems(V)));
   q.energy_blocks = 2048;
   q.max_chunks = (int32_t)(N / kDecChunk + R + 1);
   RGCN_TRY(dalloc(c, &q.loss_part, 2 * (size_t)(q.energy_blocks > q.max_chunks ? q.energy_blocks : q.max_chunks)));
@@ -719,7 +886,7 @@ void decoder_free(rgcn_ctx* c) {
   void* ptrs[] = {q.keyv, q.keyv_s, q.valv, q.permv, q.keyr, q.keyr_s, q.valr, q.permr, q.row_ptr, q.rel_ptr,
                   q.chunk_ptr, q.e_other, q.e_rel, q.e_trip, q.long_rows, q.nlong, q.dx, q.loss_part, q.loss,
                   q.slab, q.keyv_t, q.keyr_t, q.tablev, q.tabler, q.long_first, q.long_cnt, q.piece_row, q.piece_k,
-                  q.piece_slab, q.perm_pos};
+                  q.piece_slab, q.perm_pos, q.cb, q.rb, q.e_g, q.row_key, q.row_key_s, q.row_order, q.row_tab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (q.ev_ready) (void)hipEventDestroy(q.ev_ready);
@@ -765,7 +932,12 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t 
     ProfScope ps(c, "dec_ptrs", 8.0 * (V + R), 0);
     hipLaunchKernelGGL(k_dec_ptrs, dim3(1 + (V + 1 + 1023) / 1024), dim3(1024), 0, c->stream, q.keyv_s, q.keyr_s, N,
                        V, R, n_rel, copies, q.row_ptr, q.long_rows, q.nlong, q.long_cap, q.long_first, q.long_cnt, q.piece_row,
-                       q.piece_k, q.piece_cap, q.rel_ptr, q.chunk_ptr);
+                       q.piece_k, q.piece_cap, q.rel_ptr, q.chunk_ptr, q.row_key);
+  }
+  {
+    // (one 8-bit pass of the library's stable radix sort over V keys)
+    SortSpec sp{q.row_key, q.row_key_s, q.row_order, q.row_key_s, q.row_order, nullptr, q.row_tab, (int64_t)V, 255u};
+    RGCN_TRY(sort_pairs(c, "dec_row_order", 1, &sp));
   }
   if (N > 0) {
     ProfScope ps(c, "dec_slots", 40.0 * N, 0);
@@ -848,6 +1020,36 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     a.k = k;
     a.dcodes_drop = (dcodes_drop != nullptr && drop != nullptr && drop->mode != DROP_NONE) ? dcodes_drop : nullptr;
     if (drop != nullptr) a.drop = *drop; else a.drop = DropSpec{DROP_NONE, 0, 0, 1.0f, 0, nullptr, nullptr};
+    // line form (default when the rows are float4-addressable): RGCN_DEC_LINES=0 selects the full-row kernel, whose
+    // sums it reproduces bit for bit (tests/test_gpu_decoder.py::test_entity_gradient_forms_are_bitwise_equal)
+    const char* lines_env = getenv("RGCN_DEC_LINES");
+    const bool lines = vec4 && !(lines_env && atoi(lines_env) == 0) && (int64_t)V * kLine * 4 < (1ll << 32);
+    if (lines) {
+      {
+        ProfScope ps(c, "dec_band_tables", (4.0 * d + 4.0 * kLine * q.nbands) * ((double)V + R), 0);
+        const int64_t threads = ((int64_t)V + R) * q.nbands * (kLine / 4);
+        hipLaunchKernelGGL(k_dec_band_tables, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, codes, Wr, V,
+                           R, d, q.nbands, q.cb, q.rb);
+      }
+      if (N > 0)
+        hipLaunchKernelGGL(k_dec_slot_grad, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, c->stream, q.e_trip, q.dx,
+                           q.row_ptr, V, q.e_g);
+      LineArgs b;
+      b.cb = q.cb; b.rb = q.rb; b.R = R; b.nbands = q.nbands; b.e_g = q.e_g; b.row_order = q.row_order;
+      const int64_t pieces = 2 * (int64_t)N / kDecPiece + 1;
+      b.nlb = (int)std::min<int64_t>(128, std::max<int64_t>(8, (pieces + 7) / 8));
+      b.nchunks = (V + kLineRows - 1) / kLineRows;
+      const int phases = (q.nbands + 7) / 8;
+      const size_t lds = (size_t)R * kLine * sizeof(float);
+      const bool rlds = lds <= 64 * 1024;
+      dim3 grid((unsigned)(8 * phases * (b.nlb + b.nchunks))), block(256);
+      // design: one line of the partner row and of the relation row per incidence and band (what the kernel asks of the
+      // L2s) + the index lists once per band + the rows written; compulsory as for the full-row kernel
+      ProfScope ps(c, "dec_entity_grad", (8.0 * kLine + 12.0) * q.nbands * 2.0 * N + 8.0 * V * d, 6.0 * N * d,
+                   4.0 * d * (2.0 * V + R) + 32.0 * N);
+      if (rlds) hipLaunchKernelGGL((k_dec_entity_lines<true>), grid, block, lds, c->stream, a, b);
+      else hipLaunchKernelGGL((k_dec_entity_lines<false>), grid, block, 0, c->stream, a, b);
+    } else {
     const int nvec = vec4 ? d / 4 : d;
     const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
     const int rpb = kEntThreads / tpr;
@@ -866,6 +1068,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
       if (tpr == 64) RGCN_LAUNCH_EG(1, 64); else if (tpr == 128) RGCN_LAUNCH_EG(1, 128); else RGCN_LAUNCH_EG(1, 256);
     }
 #undef RGCN_LAUNCH_EG
+    }
     if (vec4) hipLaunchKernelGGL((k_dec_long_finish<4>), dim3(128), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_dec_long_finish<1>), dim3(128), dim3(256), 0, c->stream, a);
   }

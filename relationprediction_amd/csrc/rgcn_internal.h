@@ -256,6 +256,13 @@ struct DecoderBufs {
   float* piece_slab = nullptr;                         // [piece_cap][d] partial sums of the pieces
   int32_t long_cap = 0, piece_cap = 0, max_chunks = 0, energy_blocks = 0;
   float *dx = nullptr, *loss_part = nullptr, *slab = nullptr;
+  // band-major, line-aligned copies of the codes and of W_relation for the line form of the entity gradient
+  // (decoder.hip, k_dec_entity_lines): [bands][V][32] and [bands][R][32], bands = ceil(d / 32); rebuilt every call
+  float *cb = nullptr, *rb = nullptr, *e_g = nullptr;   // e_g: the loss gradient of every incidence slot
+  uint32_t *row_key = nullptr, *row_key_s = nullptr;    // rows by descending number of incidences (one radix pass)
+  int32_t* row_order = nullptr;
+  uint16_t* row_tab = nullptr;
+  int32_t nbands = 0;
   double* loss = nullptr;
   uint32_t *keyv_t = nullptr, *keyr_t = nullptr;   // sort scratch (csr_sort.hip)
   uint16_t *tablev = nullptr, *tabler = nullptr;

@@ -67,6 +67,50 @@ def test_device_decoder_matches_oracle(native, V, R, d, nb, E, hub):
         assert_close(grads[k], og[k], rel=5e-4, name=k)
 
 
+def _decoder_grads(native, V, R, d, nb, X, Y, lines, top_dropout=0.0, seed=3):
+    """loss, dL/dcodes (and its dropped copy's consumer: the encoder's gradients) with the entity-gradient form chosen"""
+    import os
+    L = 1
+    params, triples, _, _ = make_case(V, R, d, L, "block", nb, 4 * V, seed=seed)
+    old = os.environ.get("RGCN_DEC_LINES")
+    os.environ["RGCN_DEC_LINES"] = "1" if lines else "0"
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=len(triples))
+    try:
+        eng.set_params(params)
+        eng.set_graph(triples)
+        eng.forward(train=False)
+        eng.decoder_reserve(len(X))
+        xd, yd = eng.to_device(X), eng.to_device(Y)
+        eng.decoder_loss_backward_device(xd, yd, len(X), 0.01)
+        out = eng.loss(), eng.dcodes(), eng.get_grad("W_relation")
+        xd.free(); yd.free()
+    finally:
+        eng.close()
+        if old is None:
+            os.environ.pop("RGCN_DEC_LINES", None)
+        else:
+            os.environ["RGCN_DEC_LINES"] = old
+    return out
+
+
+@pytest.mark.parametrize("V,R,d,nb,n,hub", [(60, 7, 20, 4, 200, None), (120, 9, 40, 8, 3000, 5), (700, 600, 72, 9, 9000, 7),
+                                            (257, 5, 520, 104, 4000, 3), (14541, 237, 500, 100, 60000, 11)])
+def test_entity_gradient_forms_are_bitwise_equal(native, V, R, d, nb, n, hub):
+    """k_dec_entity_lines (column bands of one cache line over a band-major copy of the codes, one band per XCD and
+    pass) forms every sum of dL/dcodes in k_dec_entity_grad's order: bit-equal, rows of every length (empty, short,
+    > 256 incidences = pieces), R small (LDS table) and large (global table), d with a partial last band."""
+    rng = np.random.RandomState(n)
+    pos = np.stack([rng.randint(0, V, n), rng.randint(0, R, n), rng.randint(0, V, n)], 1).astype(np.int32)
+    pos[rng.rand(n) < 0.3, 0] = rng.randint(0, max(2, V // 10))      # a skewed subject distribution
+    X, Y = decoder_batch(rng, pos, V, neg_rate=2, hub=hub)
+    a = _decoder_grads(native, V, R, d, nb, X, Y, lines=False)
+    b = _decoder_grads(native, V, R, d, nb, X, Y, lines=True)
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]), float(np.abs(a[1] - b[1]).max())
+    assert np.array_equal(a[2], b[2])
+    assert np.abs(a[1]).max() > 0
+
+
 @pytest.mark.parametrize("V,R,n,rate", [(300, 7, 900, 10), (1400, 1345, 13000, 1)])
 def test_decoder_on_a_tiled_batch(native, V, R, n, rate):
     """A batch the device negative sampler tiled (NegativeSampler.transform's layout) is sorted by (relation, row mod
