@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(1024) k_dec_ptrs(const uint32_t* __restrict__ 
   row_ptr[v] = beg;
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, 2 * N, (uint32_t)(v + 1));
-  // sort key of the line form's row order: descending length (long rows, which it skips, in front)
-  row_key[v] = end - beg > kDecLongRow ? 0u : (uint32_t)(255 - min(end - beg, 255));
+  // sort key of the line form's row order: descending length (long rows, which it skips, at the end)
+  row_key[v] = end - beg > kDecLongRow ? 255u : (uint32_t)(255 - min(end - beg, 255));
   if (end - beg > kDecLongRow) {
     // pieces of one row get consecutive ids, so the finishing pass adds them in a fixed order whatever
     // order the rows were registered in
@@ -439,15 +439,14 @@ __global__ void __launch_bounds__(256) k_dec_long_finish(EntArgs a) {
 // bit; pieces of long rows: eight interleaved slot groups, their partial sums added in group order, as there.  The band
 // of W_relation ([R][32], 30 KB at R = 237) sits in LDS when it fits.
 constexpr int kLine = 32;                 // floats per (row, band)
-constexpr int kLineTurns = 4;             // turns of eight rows per wavefront
-constexpr int kLineRows = 4 * kLineTurns * 8;   // rows per workgroup
+constexpr int kLineWaves = 4;             // wavefronts per workgroup
 
 struct LineArgs {
   const float* cb;          // [bands][V][32]
   const float* rb;          // [bands][R][32]
   const float* e_g;         // loss gradient of every incidence slot
   const int32_t* row_order; // rows by descending number of incidences
-  int32_t R, nbands, nlb, nchunks;
+  int32_t R, nbands;
 };
 
 __global__ void __launch_bounds__(256) k_dec_band_tables(const float* __restrict__ codes, const float* __restrict__ Wr,
@@ -482,33 +481,41 @@ __device__ __forceinline__ void line_range(const EntArgs& a, const float* __rest
   float gg = 0.f;
   if (cl < n) {
     const int s = s0 + cl * step;
-    oth = (uint32_t)a.e_other[s] * (kLine * 4); rel = (uint32_t)a.e_rel[s] * (kLine * 4); gg = e_g[s];
+    oth = (uint32_t)a.e_other[s]; rel = (uint32_t)a.e_rel[s]; gg = e_g[s];
   }
   const uint32_t cb16 = (uint32_t)cl * 16;
   for (int base = 0; base < n; base += 8) {
     const uint32_t co = oth, cr = rel;
     const float cg = gg;
-    float4 u[8], w[8];
-    float gt[8];
+    constexpr int BLK = 8;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const uint32_t ot = __shfl(co, g * 8 + t, 64), rt = __shfl(cr, g * 8 + t, 64);
-      gt[t] = __shfl(cg, g * 8 + t, 64);
-      u[t] = *reinterpret_cast<const float4*>(cbb + (ot + cb16));
-      if constexpr (RLDS) w[t] = *reinterpret_cast<const float4*>(rl + (rt + cb16));
-      else w[t] = *reinterpret_cast<const float4*>(rbb + (rt + cb16));
-    }
-    oth = 0; rel = 0; gg = 0.f;
-    if (base + 8 + cl < n) {
-      const int s = s0 + (base + 8 + cl) * step;
-      oth = (uint32_t)a.e_other[s] * (kLine * 4); rel = (uint32_t)a.e_rel[s] * (kLine * 4); gg = e_g[s];
-    }
+    for (int h = 0; h < 8; h += BLK) {
+      float4 u[BLK], w[BLK];
+      float gt[BLK];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      acc[0] = fmaf(gt[t] * u[t].x, w[t].x, acc[0]);
-      acc[1] = fmaf(gt[t] * u[t].y, w[t].y, acc[1]);
-      acc[2] = fmaf(gt[t] * u[t].z, w[t].z, acc[2]);
-      acc[3] = fmaf(gt[t] * u[t].w, w[t].w, acc[3]);
+      for (int t = 0; t < BLK; ++t) {
+        const uint32_t ot = (uint32_t)__shfl((int)co, g * 8 + h + t, 64) * (kLine * 4), rt = (uint32_t)__shfl((int)cr, g * 8 + h + t, 64) * (kLine * 4);
+        gt[t] = __shfl(cg, g * 8 + h + t, 64);
+        u[t] = *reinterpret_cast<const float4*>(cbb + (ot + cb16));
+        if constexpr (RLDS) w[t] = *reinterpret_cast<const float4*>(rl + (rt + cb16));
+        else w[t] = *reinterpret_cast<const float4*>(rbb + (rt + cb16));
+      }
+      if (h + BLK == 8) {
+        oth = 0; rel = 0; gg = 0.f;
+        if (base + 8 + cl < n) {
+          const int s = s0 + (base + 8 + cl) * step;
+          // (raw indices: nothing may consume the loaded values before the next block's shuffles, or the wait for them
+          // -- and, the memory counter retiring in order, for this block's lines -- lands here)
+          oth = (uint32_t)a.e_other[s]; rel = (uint32_t)a.e_rel[s]; gg = e_g[s];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < BLK; ++t) {
+        acc[0] = fmaf(gt[t] * u[t].x, w[t].x, acc[0]);
+        acc[1] = fmaf(gt[t] * u[t].y, w[t].y, acc[1]);
+        acc[2] = fmaf(gt[t] * u[t].z, w[t].z, acc[2]);
+        acc[3] = fmaf(gt[t] * u[t].w, w[t].w, acc[3]);
+      }
     }
   }
 }
@@ -520,27 +527,34 @@ __global__ void k_dec_slot_grad(const int32_t* __restrict__ e_trip, const float*
   if (s < row_ptr[V]) e_g[s] = dx[e_trip[s]];
 }
 
+// Persistent workgroups: gridDim = 8 x (workgroups per XCD); workgroup (x, q) takes band x of every row, then band
+// x + 8, ...: one fill of the relation band per workgroup and pass, and every wavefront of an XCD moves to the next band
+// at about the same time.  Inside a pass the band's W wavefronts are dealt the work units round-robin: first the pieces
+// of long rows (from the LAST wavefront down: the first ones get the longest short rows), then the turns of eight short
+// rows in the order of descending length (b.row_order) -- turn w, w + W, w + 2 W, ... for wavefront w, so every
+// wavefront gets long turns and short ones; the next turn's rows and row pointers are requested a turn ahead.
 template <bool RLDS>
-__global__ void __launch_bounds__(256) k_dec_entity_lines(EntArgs a, LineArgs b) {
+__global__ void __launch_bounds__(64 * kLineWaves) k_dec_entity_lines(EntArgs a, LineArgs b) {
   extern __shared__ float rl[];                       // RLDS: this band of W_relation, [R][32]
-  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int per = b.nlb + b.nchunks;
-  const int band = (j / per) * 8 + x, within = j % per;
-  if (band >= b.nbands) return;
-  const char* __restrict__ cbb = reinterpret_cast<const char*>(b.cb + (size_t)band * a.V * kLine);
-  const char* __restrict__ rbb = reinterpret_cast<const char*>(b.rb + (size_t)band * b.R * kLine);
-  if constexpr (RLDS) {
-    for (int i = threadIdx.x; i < b.R * (kLine / 4); i += 256)
-      reinterpret_cast<float4*>(rl)[i] = reinterpret_cast<const float4*>(rbb)[i];
-    __syncthreads();
-  }
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, cl = lane & 7;
-  const int col = band * kLine + cl * 4;
-  const bool colok = col < a.d;                       // d % 4 == 0: the whole float4 is inside the row, or none of it
-  if (within < b.nlb) {
-    // pieces of long rows: one piece per wavefront and turn, eight interleaved slot groups
-    const int n = a.nlong[1];
-    for (int lb = within * 4 + wave; lb < n; lb += b.nlb * 4) {
+  const int W = (gridDim.x >> 3) * kLineWaves, w = q * kLineWaves + wave;
+  const int npieces = a.nlong[1], nturns = (a.V + 7) >> 3;
+  for (int band = x, pass = 0; band < b.nbands; band += 8, ++pass) {
+    const char* __restrict__ cbb = reinterpret_cast<const char*>(b.cb + (size_t)band * a.V * kLine);
+    const char* __restrict__ rbb = reinterpret_cast<const char*>(b.rb + (size_t)band * b.R * kLine);
+    // the first turn's rows: requested before the relation band is copied
+    int slot = w * 8 + g, v_n = -1, beg_n = 0, end_n = 0;
+    if (slot < a.V) { v_n = b.row_order[slot]; beg_n = a.row_ptr[v_n]; end_n = a.row_ptr[v_n + 1]; }
+    if constexpr (RLDS) {
+      if (pass > 0) __syncthreads();                  // every wavefront is done with the previous band
+      for (int i = threadIdx.x; i < b.R * (kLine / 4); i += 64 * kLineWaves)
+        reinterpret_cast<float4*>(rl)[i] = reinterpret_cast<const float4*>(rbb)[i];
+      __syncthreads();
+    }
+    const int col = band * kLine + cl * 4;
+    const bool colok = col < a.d;                     // d % 4 == 0: the whole float4 is inside the row, or none of it
+    for (int lb = W - 1 - w; lb < npieces; lb += W) {
       const int v = a.piece_row[lb];
       const int beg = a.row_ptr[v] + a.piece_k[lb] * kDecPiece;
       const int end = min(a.row_ptr[v + 1], beg + kDecPiece);
@@ -555,33 +569,22 @@ __global__ void __launch_bounds__(256) k_dec_entity_lines(EntArgs a, LineArgs b)
       }
       if (g == 0 && colok) vstore<4>(a.piece_slab + (size_t)lb * a.d + col, t);
     }
-    return;
-  }
-  // short rows in the order of descending length (b.row_order), eight per turn; turn t of wavefront w is the
-  // (t W + w)-th group of eight, W = the band's wavefronts: every wavefront gets long turns and short ones
-  const int W = b.nchunks * 4, wid = (within - b.nlb) * 4 + wave;
-  int vs[kLineTurns], beg[kLineTurns], end[kLineTurns];
-#pragma unroll
-  for (int t = 0; t < kLineTurns; ++t) {
-    const int slot = (t * W + wid) * 8 + g;
-    vs[t] = -1; beg[t] = end[t] = 0;
-    if (slot < a.V) {
-      vs[t] = b.row_order[slot];
-      beg[t] = a.row_ptr[vs[t]]; end[t] = a.row_ptr[vs[t] + 1];
+    for (int turn = w; turn < nturns; turn += W) {
+      const int v = v_n, beg = beg_n, end = end_n;
+      slot += W * 8;
+      v_n = -1; beg_n = end_n = 0;
+      if (turn + W < nturns && slot < a.V) { v_n = b.row_order[slot]; beg_n = a.row_ptr[v_n]; end_n = a.row_ptr[v_n + 1]; }
+      if (v < 0 || end - beg > kDecLongRow) continue;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      line_range<RLDS>(a, b.e_g, cbb, rbb, reinterpret_cast<const char*>(rl), beg, end, 1, g, cl, acc);
+      const float4 self = *reinterpret_cast<const float4*>(cbb + ((size_t)v * kLine + cl * 4) * sizeof(float));
+      const float kc = a.k * (float)(end - beg);
+      acc[0] = fmaf(kc, self.x, acc[0]);
+      acc[1] = fmaf(kc, self.y, acc[1]);
+      acc[2] = fmaf(kc, self.z, acc[2]);
+      acc[3] = fmaf(kc, self.w, acc[3]);
+      if (colok) store_dcodes<4>(a, (size_t)v * a.d + col, acc);
     }
-  }
-#pragma unroll
-  for (int t = 0; t < kLineTurns; ++t) {
-    if (vs[t] < 0 || end[t] - beg[t] > kDecLongRow) continue;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    line_range<RLDS>(a, b.e_g, cbb, rbb, reinterpret_cast<const char*>(rl), beg[t], end[t], 1, g, cl, acc);
-    const float4 self = *reinterpret_cast<const float4*>(cbb + ((size_t)vs[t] * kLine + cl * 4) * sizeof(float));
-    const float kc = a.k * (float)(end[t] - beg[t]);
-    acc[0] = fmaf(kc, self.x, acc[0]);
-    acc[1] = fmaf(kc, self.y, acc[1]);
-    acc[2] = fmaf(kc, self.z, acc[2]);
-    acc[3] = fmaf(kc, self.w, acc[3]);
-    if (colok) store_dcodes<4>(a, (size_t)vs[t] * a.d + col, acc);
   }
 }
 
@@ -863,6 +866,12 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.nlong, 2));
   RGCN_TRY(dalloc(c, &q.dx, N));
   q.nbands = (int32_t)((d + kLine - 1) / kLine);
+  {
+    int dev = 0, cus = 0;
+    RGCN_HIP(c, hipGetDevice(&dev));
+    RGCN_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    q.cus = cus > 0 ? cus : 256;
+  }
   RGCN_TRY(dalloc(c, &q.cb, (size_t)q.nbands * V * kLine));
   RGCN_TRY(dalloc(c, &q.rb, (size_t)q.nbands * R * kLine));
   RGCN_TRY(dalloc(c, &q.e_g, 2 * N));
@@ -1036,13 +1045,12 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
                            q.row_ptr, V, q.e_g);
       LineArgs b;
       b.cb = q.cb; b.rb = q.rb; b.R = R; b.nbands = q.nbands; b.e_g = q.e_g; b.row_order = q.row_order;
-      const int64_t pieces = 2 * (int64_t)N / kDecPiece + 1;
-      b.nlb = (int)std::min<int64_t>(128, std::max<int64_t>(8, (pieces + 7) / 8));
-      b.nchunks = (V + kLineRows - 1) / kLineRows;
-      const int phases = (q.nbands + 7) / 8;
       const size_t lds = (size_t)R * kLine * sizeof(float);
       const bool rlds = lds <= 64 * 1024;
-      dim3 grid((unsigned)(8 * phases * (b.nlb + b.nchunks))), block(256);
+      // persistent workgroups: three per CU (measured: 768 workgroups 123 us, 1,024: 127, 512: 132), a multiple of 8
+      static const int wgs_env = getenv("RGCN_DEC_WGS") ? atoi(getenv("RGCN_DEC_WGS")) : 0;
+      const int wgs = wgs_env > 0 ? wgs_env : 12 / kLineWaves * q.cus;
+      dim3 grid((unsigned)((wgs + 7) / 8 * 8)), block(64 * kLineWaves);
       // design: one line of the partner row and of the relation row per incidence and band (what the kernel asks of the
       // L2s) + the index lists once per band + the rows written; compulsory as for the full-row kernel
       ProfScope ps(c, "dec_entity_grad", (8.0 * kLine + 12.0) * q.nbands * 2.0 * N + 8.0 * V * d, 6.0 * N * d,

@@ -262,7 +262,7 @@ struct DecoderBufs {
   uint32_t *row_key = nullptr, *row_key_s = nullptr;    // rows by descending number of incidences (one radix pass)
   int32_t* row_order = nullptr;
   uint16_t* row_tab = nullptr;
-  int32_t nbands = 0;
+  int32_t nbands = 0, cus = 0;     // cus: compute units of the device (persistent workgroups of the line kernel)
   double* loss = nullptr;
   uint32_t *keyv_t = nullptr, *keyr_t = nullptr;   // sort scratch (csr_sort.hip)
   uint16_t *tablev = nullptr, *tabler = nullptr;
