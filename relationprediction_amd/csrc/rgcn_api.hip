@@ -723,9 +723,12 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // layer's chain has nothing to overlap with, and the two independent kernels (relation-weight gradients, dW_self)
     // beside it only stretch it: 0.589-0.599 ms per step serial against 0.595-0.610 with them on side streams
     // (tools/gpu_sched_ab.sh, three boxes).  Sharded runs keep the side streams (the all-gather rides on one).
-    static const int rows_serial_env = getenv("RGCN_ROWS_SERIAL") ? atoi(getenv("RGCN_ROWS_SERIAL")) : 1;
+    // At the training graph's size (272,115 edges: the message-gradient kernel is five GEMMs long) the side stream
+    // pays again -- 2.50 ms per step against 2.54 (tools/gpu_traingraph_ab.sh) -- so the default goes by the graph:
+    // RGCN_ROWS_SERIAL unset: main stream up to 65,536 edges; 1 / 0 force either.
+    static const int rows_serial_env = getenv("RGCN_ROWS_SERIAL") ? atoi(getenv("RGCN_ROWS_SERIAL")) : -1;
     static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
-    const bool serial = rows_serial_env != 0 && c->world == 1;
+    const bool serial = c->world == 1 && (rows_serial_env < 0 ? c->g.E <= 65536 : rows_serial_env != 0);
     const bool aux_saved = c->use_aux;
     const bool corun = corun_env != 0 && aux_saved && c->world == 1;
     if (serial) c->use_aux = false;
@@ -733,7 +736,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       StreamScope side(c, 0);
       RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-      if (!corun) RGCN_TRY(block_dw_reduce(c, l));
+      if (!(corun && serial)) RGCN_TRY(block_dw_reduce(c, l));     // (behind its producer, on whichever stream that is)
       c->dw_pending = side.active;
     }
     if (corun) {
@@ -746,7 +749,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       c->use_aux = true;
       {
         StreamScope side(c, 1);
-        RGCN_TRY(block_dw_reduce(c, l));
+        if (serial) RGCN_TRY(block_dw_reduce(c, l));
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                           lb.gwself, d, auto_split_k(d, d, rows)));
       }
