@@ -1003,7 +1003,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
     // beside the entity gradient (forked right behind the energy kernel) and the encoder's backward pass (the caller
     // joins it: stream_join(c, 2))
-    StreamScope side(c, 2);
+    StreamScope side(c, 2, 2);
     // the loss itself (one workgroup summing the kernel's partials) is nobody's input on the device: it goes there too
     hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, fused ? q.max_chunks : q.energy_blocks,
                        Nt, d, reg_param, q.loss);

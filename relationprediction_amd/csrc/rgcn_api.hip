@@ -46,8 +46,10 @@ ProfScope::~ProfScope() {
   if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, c->stream);
 }
 
-StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), active(false) {
-  if (k < 0 || !c->use_aux || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
+StreamScope::StreamScope(rgcn_ctx* ctx, int k, int in_capture) : c(ctx), saved(ctx->stream), active(false) {
+  static const int cap_forks_env = getenv("RGCN_CAPTURE_FORKS") ? atoi(getenv("RGCN_CAPTURE_FORKS")) : 1;
+  const bool on = c->use_aux || ((in_capture & cap_forks_env) != 0 && c->capturing && c->use_aux_before_capture && c->world == 1);
+  if (k < 0 || !on || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
   if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess) return;
   if (hipStreamWaitEvent(c->aux[k], c->ev_fork, 0) != hipSuccess) return;
   c->stream = c->aux[k];
@@ -57,9 +59,9 @@ StreamScope::StreamScope(rgcn_ctx* ctx, int k) : c(ctx), saved(ctx->stream), act
 StreamScope::~StreamScope() { c->stream = saved; }
 
 rgcn_status stream_join(rgcn_ctx* c, int k) {
-  if (!c->use_aux || c->stream != c->main_stream) return RGCN_OK;   // nothing was forked
+  if (c->stream != c->main_stream) return RGCN_OK;
   // a join costs the main stream ~3.6 us even when the side stream is idle (tools/anyorder_probe.hip): skip it when
-  // nothing went to that stream since its last join
+  // nothing went to that stream since its last join (side streams switched off, or no fork taken)
   if (!c->aux_dirty[k]) return RGCN_OK;
   c->aux_dirty[k] = false;
   RGCN_HIP(c, hipEventRecord(c->ev_join[k], c->aux[k]));
@@ -73,6 +75,7 @@ static rgcn_status sync_all(rgcn_ctx* c) {
   for (int k = 0; k < kAuxStreams; ++k)
     if (c->aux[k]) RGCN_HIP(c, hipStreamSynchronize(c->aux[k]));
   RGCN_HIP(c, hipStreamSynchronize(c->main_stream));
+  for (int k = 0; k < kAuxStreams; ++k) c->aux_dirty[k] = false;     // nothing left to join
   return RGCN_OK;
 }
 
@@ -730,7 +733,11 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
     const bool serial = c->world == 1 && (rows_serial_env < 0 ? c->g.E <= 65536 : rows_serial_env != 0);
     const bool aux_saved = c->use_aux;
-    const bool corun = corun_env != 0 && aux_saved && c->world == 1;
+    // (a captured step is a chain -- rgcn_capture_begin -- with two exceptions: the decoder's preparation and this
+    // pairing, RGCN_CAPTURE_FORKS bit 1: 1.004-1.023 ms per replayed train step against 1.029-1.033 without it; the
+    // decoder's relation-gradient reduce forked as well, bit 2: 1.015-1.041 -- tools/gpu_capture_forks_ab.sh)
+    const bool cap_fork = c->capturing && c->use_aux_before_capture && c->world == 1 && serial;
+    const bool corun = corun_env != 0 && (aux_saved || cap_fork) && c->world == 1;
     if (serial) c->use_aux = false;
     {
       StreamScope side(c, 0);
@@ -746,9 +753,9 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       // dH GEMM's start.  0.566-0.574 ms per step against 0.580-0.587 with only the GEMMs paired and 0.597-0.599 with
       // everything one behind the other (tools/gpu_corun_ab.sh); the message-gradient kernel itself beside the GEMMs
       // (either end of the side stream) loses 8-10 us again.
-      c->use_aux = true;
+      c->use_aux = aux_saved;
       {
-        StreamScope side(c, 1);
+        StreamScope side(c, 1, 1);
         if (serial) RGCN_TRY(block_dw_reduce(c, l));
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                           lb.gwself, d, auto_split_k(d, d, rows)));
@@ -767,6 +774,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     c->use_aux = aux_saved;
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
+
   } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
     // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
@@ -1252,10 +1260,6 @@ static rgcn_status train_step_tail(rgcn_ctx* c, const int32_t* X_dev, const floa
     const rgcn_status ps = decoder_prepare(c, X_loc, n_loc, N);
     c->stream = c->main_stream;
     RGCN_TRY(ps);
-    if (fork_in_capture) {       // (stream_join is a no-op while the side streams are switched off)
-      RGCN_HIP(c, hipEventRecord(c->ev_join[1], c->aux[1]));
-      RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[1], 0));
-    }
   } else {
     RGCN_TRY(decoder_prepare(c, X_loc, n_loc, N));
   }

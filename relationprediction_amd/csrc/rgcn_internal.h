@@ -431,7 +431,9 @@ struct StreamScope {
   rgcn_ctx* c;
   hipStream_t saved;
   bool active;
-  StreamScope(rgcn_ctx* ctx, int k);
+  // in_capture: the fork is also taken while a step is being captured (a captured step is otherwise one chain: the
+  // side streams are switched off for the capture, rgcn_capture_begin)
+  StreamScope(rgcn_ctx* ctx, int k, int in_capture = 0);       // in_capture: bit of RGCN_CAPTURE_FORKS that allows it
   ~StreamScope();
 };
 rgcn_status stream_join(rgcn_ctx* c, int k);
