@@ -131,10 +131,18 @@ static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_lis
   c->params.push_back(p);
 }
 
-static int auto_split_k(int M, int N, int K) {
+// target: workgroups of a split-K launch.  256 since the dW_self GEMM runs beside the dH GEMM (the backward layer's
+// pairing): 0.559 ms per step at 256 / 320, 0.572-0.580 at 512 (the figure of rounds 1-3, when it ran alone), 0.578-0.585
+// at 768, 0.588 at 192, 0.655 at 128 (tools/gpu_splitk_ab.sh); WN18 sizes 1.128 against 1.166.  `wide`: 512 after all --
+// with FB15k's 1,345 relations the slab reduce of the relation weights' gradients (6.7 M floats) leads the GEMM on the
+// side stream, and the GEMM has to be short: 0.645 ms per step against 0.680.  The rule reads the model's dimensions
+// only, one figure for every form of the layer: the split decides the summation order of dW_self, and the forms are
+// held bitwise equal to each other.
+static int auto_split_k(int M, int N, int K, bool wide = false) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   if (tiles >= 192) return 1;
-  static const int target = getenv("RGCN_SPLITK_TARGET") ? atoi(getenv("RGCN_SPLITK_TARGET")) : 512;
+  static const int target_env = getenv("RGCN_SPLITK_TARGET") ? atoi(getenv("RGCN_SPLITK_TARGET")) : 0;
+  const int target = target_env > 0 ? target_env : (wide ? 512 : 256);
   int s = (target + tiles - 1) / tiles;
   const int max_by_k = (K + 127) / 128;   // at least 128 of K per slab
   if (s > max_by_k) s = max_by_k;
@@ -698,6 +706,8 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   const int rows = hi - lo;
   LayerBufs& lb = c->layers[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
+  // (see auto_split_k: a long slab reduce of the relation weights' gradients in front of the dW_self GEMM)
+  const bool wide_dw = c->kind == RGCN_KIND_BLOCK && (double)2 * c->R * c->d * (c->d / c->nb) > 4e6;
   static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
 
   // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
@@ -758,7 +768,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
         StreamScope side(c, 1, 1);
         if (serial) RGCN_TRY(block_dw_reduce(c, l));
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows)));
+                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                         c->self_buf + (size_t)lo * d, d, 1));
@@ -768,7 +778,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       {
         StreamScope side(c, 1);
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows)));
+                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
       }
     }
     c->use_aux = aux_saved;
@@ -787,7 +797,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
     }
     GemmEpilogue e;
     e.mode = 2;
@@ -811,7 +821,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     if (sched == 0) {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
     }
     // G = dS . W_self^T
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
@@ -819,7 +829,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     if (sched == 2) {   // dW_self = H_in^T . dS on side stream 1, queued behind the dH GEMM
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
     }
     if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
     a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
@@ -829,7 +839,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
     if (sched == 1)
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
   } else {
     const int zc = 2 * c->B * d;
     // The four dense contractions of the layer depend on D_l / dS_l only.  Two of them -- the weight gradients dW_self =
@@ -840,7 +850,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     {
       StreamScope side(c, corun_env ? 1 : -1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
       // dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
       RGCN_TRY(wait_gather(c));            // D_l of every row
       RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
