@@ -748,6 +748,30 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // decoder's relation-gradient reduce forked as well, bit 2: 1.015-1.041 -- tools/gpu_capture_forks_ab.sh)
     const bool cap_fork = c->capturing && c->use_aux_before_capture && c->world == 1 && serial;
     const bool corun = corun_env != 0 && (aux_saved || cap_fork) && c->world == 1;
+    // RGCN_BWD_LATE_DW (default 1): the message-gradient kernel of the relation weights is forked BEHIND the dH GEMM and
+    // runs beside the row-gradient kernel -- two gather kernels, each bound by the latency of its gathers and neither by
+    // bytes, share the chip better than either does with a GEMM -- and is joined at the end of the layer: 0.553-0.556 ms
+    // per step against 0.560-0.566 with it in front of the GEMMs on the main stream; joined a layer later: 0.563-0.568
+    // (tools/gpu_env_ab.sh).  Captured steps keep the chain + GEMM pairing.
+    static const int late_dw_env = getenv("RGCN_BWD_LATE_DW") ? atoi(getenv("RGCN_BWD_LATE_DW")) : 1;
+    const bool late_dw = late_dw_env != 0 && corun && serial && aux_saved && !c->capturing && rows_layer(c);
+    if (late_dw) {
+      {
+        StreamScope side(c, 1);
+        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+      }
+      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                        c->self_buf + (size_t)lo * d, d, 1));
+      {
+        StreamScope side(c, 0);
+        RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
+        RGCN_TRY(block_dw_reduce(c, l));
+      }
+      RGCN_TRY(single_pass(c, "block_rows_bwd", l, true, c->bwd_D, a));
+      RGCN_TRY(stream_join(c, 0));
+      c->dw_pending = false;
+    } else {
     if (serial) c->use_aux = false;
     {
       StreamScope side(c, 0);
@@ -784,6 +808,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     c->use_aux = aux_saved;
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
+    }
 
   } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
