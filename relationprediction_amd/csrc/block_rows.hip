@@ -66,6 +66,9 @@ struct RowsArgs {
   int32_t V, d, nb, relu, row_lo, row_hi;
   int32_t n_long_wg;         // workgroups per band that walk the long-row / piece lists (they lead the grid)
   int32_t rows_per_wg;       // rows of one short-row workgroup
+  int32_t giant_len;         // rows with more slots are giant rows (summed piece by piece); INT_MAX when the cut is off
+  float* colpart;            // optional [gridDim / 8][d]: the column sums of `out` over the rows of workgroup j (every band's
+                             // workgroup j writes its columns of row j) -- db_emb without a pass over dL/dH0
 };
 
 constexpr int kRowsThreads = 256;
@@ -343,7 +346,7 @@ __device__ __forceinline__ void wg_long_sum(const RowsArgs& a, int beg, int end,
   __syncthreads();
 }
 
-template <int SD, bool BWD, int GW>
+template <int SD, bool BWD, int GW, bool CS>
 __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
 #pragma clang fp contract(off)
   constexpr int NG = 64 / GW;
@@ -356,6 +359,13 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   const int nbx = b1 - b0;
   if (nbx <= 0) return;
   const bool lane_ok = li < nbx;
+  // CS: this lane's columns of `out`, summed over the rows it stores -- in LDS, a private slot per thread (five more
+  // registers would cost the kernel its fourth wavefront per SIMD)
+  __shared__ float cs[CS ? kRowsThreads * SD : 1];
+  if constexpr (CS) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) cs[threadIdx.x * SD + i] = 0.0f;
+  }
   const int b = b0 + (lane_ok ? li : nbx - 1);       // idle lanes shadow the band's last block (loads only)
   const int col = b * SD;
   const float4* wq = reinterpret_cast<const float4*>(a.W) + ((size_t)x * nt_of(SD)) * GW + li;
@@ -365,10 +375,14 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   if (j < a.n_long_wg) {
     // ---- long rows and giant-row pieces: one workgroup each
     const bool writer = threadIdx.x < GW && lane_ok;
-    const int n = *a.nlong;
+    // the long rows in the order of their vertex ids: the tail of row_order (stable sort, the long rows' key is the
+    // largest).  GraphBufs::long_rows lists the same rows in the order their threads registered them, which differs
+    // from run to run -- harmless for the rows themselves, not for the column sums a workgroup forms over ITS rows.
+    const int n = *a.nlong + (a.ngiant != nullptr ? a.ngiant[0] : 0);
     for (int idx = j; idx < n; idx += a.n_long_wg) {
-      const int v = a.long_rows[idx];
+      const int v = a.row_order[a.V - n + idx];
       const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+      if (end - beg > a.giant_len) continue;          // a giant row: its pieces, below
       const size_t off = (size_t)v * a.d + col;
       float tot[SD], sum[SD];
       RowRegs<SD> rr;
@@ -381,6 +395,10 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
         RowOut<SD> ro;
         row_epilogue<SD>(a, key2, rr, off, tot, true, ro);
         row_store<SD>(a, ro);
+        if constexpr (CS) {
+#pragma unroll
+          for (int i = 0; i < SD; ++i) cs[threadIdx.x * SD + i] += ro.o.v[i];
+        }
       }
     }
     if (a.ngiant != nullptr) {
@@ -397,6 +415,14 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
           for (int i = 0; i < SD; ++i) o.v[i] = sum[i];
           *reinterpret_cast<FloatN<SD>*>(a.giant_slab + (size_t)p * a.d + col) = o;
         }
+      }
+    }
+    if constexpr (CS) {
+      if (writer) {
+        FloatN<SD> o;
+#pragma unroll
+        for (int i = 0; i < SD; ++i) o.v[i] = cs[threadIdx.x * SD + i];
+        *reinterpret_cast<FloatN<SD>*>(a.colpart + (size_t)j * a.d + col) = o;
       }
     }
     return;
@@ -503,18 +529,40 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
       RowOut<SD> ro;      // (stored at once: holding it back behind the next turn's first weight request -- the memory
       row_epilogue<SD>(a, key2, rrA, offA, tot, vA >= 0 && lane_ok, ro);      // counter retires in issue order -- cost 14
       row_store<SD>(a, ro);                                                    // registers, a wavefront per SIMD, +1 us)
+      if constexpr (CS) {
+        if (ro.store) {
+#pragma unroll
+          for (int i = 0; i < SD; ++i) cs[threadIdx.x * SD + i] += ro.o.v[i];
+        }
+      }
     }
     vA = vB; begA = begB; nA = nB; iA = iB; offA = offB;
     rrA = rrB;
     rrA.has_base = rrA.has_base && vA >= 0;
     vB = vC; begB = begC; nB = nC; iB = iC;
   }
+  if constexpr (CS) {
+    // the workgroup's (wavefront, group) slots of a column in a fixed order
+    __syncthreads();
+    if (threadIdx.x < GW && lane_ok) {
+      FloatN<SD> o;
+#pragma unroll
+      for (int i = 0; i < SD; ++i) {
+        float t = 0.0f;
+        for (int q = 0; q < (kRowsThreads / 64) * NG; ++q) t += cs[(q * GW + li) * SD + i];
+        o.v[i] = t;
+      }
+      *reinterpret_cast<FloatN<SD>*>(a.colpart + (size_t)j * a.d + col) = o;
+    }
+  }
 }
 
 template <int SD, int GW>
 hipError_t launch_rows(rgcn_ctx* c, const RowsArgs& a, bool backward, int grid) {
-  if (backward) hipLaunchKernelGGL((k_block_rows<SD, true, GW>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
-  else hipLaunchKernelGGL((k_block_rows<SD, false, GW>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
+  if (backward && a.colpart != nullptr)
+    hipLaunchKernelGGL((k_block_rows<SD, true, GW, true>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
+  else if (backward) hipLaunchKernelGGL((k_block_rows<SD, true, GW, false>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_block_rows<SD, false, GW, false>), dim3((unsigned)grid), dim3(kRowsThreads), 0, c->stream, a);
   return hipGetLastError();
 }
 
@@ -578,6 +626,7 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
   a.piece_k = giant ? c->g.piece_k : nullptr;
   a.ngiant = giant ? c->g.ngiant : nullptr;
   a.giant_slab = giant ? c->giant_slab : nullptr;
+  a.giant_len = giant ? kGiantRow : 0x7fffffff;
   a.base = ca.base; a.gate = ca.gate; a.out = ca.out; a.out2 = ca.out2; a.drop = ca.drop; a.drop2 = ca.drop2;
   a.V = c->V; a.d = c->d; a.nb = c->nb; a.relu = ca.relu; a.row_lo = ca.row_lo; a.row_hi = ca.row_hi;
   static const int rpw_env = getenv("RGCN_ROWS_PER_WG") ? atoi(getenv("RGCN_ROWS_PER_WG")) : 0;
@@ -594,6 +643,17 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
   a.n_long_wg = c->g.E > 0 ? (int)std::max<int64_t>(32, std::min<int64_t>(1024, want)) : 0;
   const int n_row_wg = (c->V + a.rows_per_wg - 1) / a.rows_per_wg;
   const int grid = 8 * (a.n_long_wg + n_row_wg);
+  // column sums of the output on the way (CombineArgs::colsum: the bias gradient behind the bottom layer's row
+  // gradients): part row j = workgroup j of every band; giant rows, finished by another kernel, get rows of their own
+  a.colpart = nullptr;
+  c->colsum_parts = 0;
+  const int giant_parts = giant ? c->g.giant_cap : 0;
+  static const int colsum_env = getenv("RGCN_ROWS_COLSUM") ? atoi(getenv("RGCN_ROWS_COLSUM")) : 1;
+  if (backward && ca.colsum && colsum_env != 0 && c->colsum_part != nullptr &&
+      (size_t)(grid / 8 + giant_parts) * c->d <= c->colsum_part_floats) {
+    a.colpart = c->colsum_part;
+    c->colsum_parts = grid / 8 + giant_parts;
+  }
   const double M = 2.0 * c->g.E, P = 4.0 * c->V * c->d;
   const double Wb = 8.0 * c->R * c->nb * c->sd * c->sd;
   const double streams = (ca.base ? 1.0 : 0.0) + (ca.gate ? 1.0 : 0.0) + 1.0 + (ca.out2 ? 1.0 : 0.0);
@@ -616,6 +676,8 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
     CombineArgs f = ca;
     f.msg = nullptr; f.add = nullptr;
     RGCN_TRY(combine_giant_finish(c, f));
+    if (a.colpart != nullptr)
+      RGCN_TRY(column_sum_giant_rows(c, ca.out, a.colpart + (size_t)(grid / 8) * c->d));
   }
   return RGCN_OK;
 }

@@ -522,6 +522,39 @@ rgcn_status materialize_mask(rgcn_ctx* c, const DropSpec& ds, uint8_t* out_dev, 
   return RGCN_OK;
 }
 
+// part row of a giant row = its rank by vertex id among the giant rows (the list itself is in registration order, which
+// differs from run to run; there are a handful of them at most)
+__global__ void k_colsum_giant_rows(const float* __restrict__ out, const int32_t* __restrict__ giant_rows,
+                                    const int32_t* __restrict__ ngiant, int cap, int d, float* __restrict__ part) {
+  const int i = blockIdx.x;
+  if (i >= cap) return;
+  const int n = min(ngiant[0], cap);
+  if (i >= n) {
+    for (int k = threadIdx.x; k < d; k += blockDim.x) part[(size_t)i * d + k] = 0.0f;
+    return;
+  }
+  const int v = giant_rows[i];
+  int rank = 0;
+  for (int k = 0; k < n; ++k) rank += giant_rows[k] < v ? 1 : 0;
+  const float* row = out + (size_t)v * d;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) part[(size_t)rank * d + k] = row[k];
+}
+
+rgcn_status column_sum_giant_rows(rgcn_ctx* c, const float* out, float* part) {
+  if (!c->g.giant_on || c->g.giant_cap <= 0) return RGCN_OK;
+  hipLaunchKernelGGL(k_colsum_giant_rows, dim3((unsigned)c->g.giant_cap), dim3(256), 0, c->stream, out, c->g.giant_rows,
+                     c->g.ngiant, c->g.giant_cap, c->d, part);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
+rgcn_status column_sum_finish(rgcn_ctx* c, float* out, int nparts, int cols) {
+  ProfScope ps(c, "bias_grad_colsum", 4.0 * nparts * cols, 0);
+  hipLaunchKernelGGL(k_colsum_final, dim3((cols + 63) / 64), dim3(1024), 0, c->stream, c->colsum_part, out, nparts, cols);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
+
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols) {
   float* part = c->colsum_part;
   const int nparts = (rows + kColRowsPerBlock - 1) / kColRowsPerBlock;

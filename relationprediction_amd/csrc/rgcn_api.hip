@@ -718,6 +718,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   a.drop = make_drop(c, l, false);
   if (c->world == 1) {
     a.out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
+    a.colsum = (l - 1 == 0) ? 1 : 0;       // db_emb = the column sums of dL/dH0 * relu'(H0): partials from the kernel that writes it
     a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
     a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
     a.gate = Hin;
@@ -918,7 +919,10 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
 static rgcn_status bwd_end(rgcn_ctx* c) {
   if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
   // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
-  RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
+  // (form 3 on one GPU: the bottom layer's row-gradient kernel left the column sums of its rows as partials)
+  if (c->colsum_parts > 0) RGCN_TRY(column_sum_finish(c, c->gb_emb, c->colsum_parts, c->d));
+  else RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
+  c->colsum_parts = 0;
   c->dw_pending = false;
   return stream_join(c, 0);   // trailing per-relation dW reductions
 }

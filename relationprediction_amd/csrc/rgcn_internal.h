@@ -369,6 +369,7 @@ struct rgcn_ctx {
   uint8_t* masks = nullptr;              // [L,V,d] explicit dropout masks
   float* colsum_part = nullptr;
   size_t colsum_part_floats = 0;
+  int32_t colsum_parts = 0;    // > 0: the last block_rows backward launch left that many [d] partial rows in colsum_part
   float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
 
   rgcn::GraphBufs g;                     // ACTIVE graph structures
@@ -538,12 +539,17 @@ struct CombineArgs {
   int32_t relu;
   int32_t row_lo, row_hi;
   int32_t v_begin = 0, v_count = -1;   // rows the launch walks: [v_begin, v_begin + v_count) (v_count < 0: all V)
+  int32_t colsum = 0;    // block_rows backward: also leave the column sums of `out` as partials (rgcn_ctx::colsum_parts)
   DropSpec drop;         // applied to base
   DropSpec drop2;        // applied to out2
 };
 rgcn_status combine(rgcn_ctx* c, const char* tag, const CombineArgs& a, double alg_bytes);
 // giant rows only: prologue + the pieces in GraphBufs' piece slab (written by the caller's own kernel) + epilogue
 rgcn_status combine_giant_finish(rgcn_ctx* c, const CombineArgs& a);
+// part[i][:] = out[giant_rows[i]][:] for the graph's giant rows, zeros up to giant_cap rows (column sums: block_rows.hip)
+rgcn_status column_sum_giant_rows(rgcn_ctx* c, const float* out, float* part);
+// out[col] = the sum of the nparts partial rows in rgcn_ctx::colsum_part (k_colsum_final's fixed order)
+rgcn_status column_sum_finish(rgcn_ctx* c, float* out, int nparts, int cols);
 rgcn_status input_forward(rgcn_ctx* c);                      // H0 = relu(W_emb + b_emb)
 rgcn_status scale_dropout(rgcn_ctx* c, const float* in, float* out, const DropSpec& ds);
 rgcn_status column_sum(rgcn_ctx* c, const float* in, float* out, int rows, int cols);

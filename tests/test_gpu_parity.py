@@ -666,6 +666,12 @@ def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, h
     for l in range(3):
         np.testing.assert_array_equal(fa[l], ua[l], err_msg="H%d" % l)
     for k in fg:
+        if k == "b_emb" and mode == 3:
+            # form 3 sums the columns of dL/dH0 inside the kernel that writes it (per workgroup, then k_colsum_final's
+            # fixed order): the same terms in another, equally fixed, order
+            scale = np.abs(ug["W_emb"]).sum(axis=0).max() + 1e-30
+            assert np.abs(fg[k] - ug[k]).max() <= 2e-6 * scale, k
+            continue
         np.testing.assert_array_equal(fg[k], ug[k], err_msg=k)
     assert np.isfinite(fa[2]).all() and (E == 0 or np.abs(fg["W_f1"]).max() > 0)
 
@@ -690,6 +696,12 @@ def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
     for form in (0, 1):
         np.testing.assert_array_equal(out[form][0], out[2][0])
         for k in out[form][1]:
+            if k == "b_emb" and form == 1:       # form 3: column sums from the row-gradient kernel (giant rows included)
+                scale = np.abs(out[2][1]["W_emb"]).sum(axis=0).max() + 1e-30
+                assert np.abs(out[form][1][k] - out[2][1][k]).max() <= 2e-6 * scale
+                got = out[form][1]["W_emb"].astype(np.float64).sum(axis=0)
+                assert np.abs(out[form][1][k] - got).max() <= 2e-6 * scale
+                continue
             np.testing.assert_array_equal(out[form][1][k], out[2][1][k], err_msg=k)
     # 2R x sd^2 floats = 2 * 3000 * 25 * 4 B = 600 KB: no LDS table -> form 0 under the hood, still correct
     V, R, d, nb, E = 200, 3000, 10, 2, 500
