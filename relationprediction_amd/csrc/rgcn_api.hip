@@ -131,18 +131,19 @@ static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_lis
   c->params.push_back(p);
 }
 
-// target: workgroups of a split-K launch.  256 since the dW_self GEMM runs beside the dH GEMM (the backward layer's
-// pairing): 0.559 ms per step at 256 / 320, 0.572-0.580 at 512 (the figure of rounds 1-3, when it ran alone), 0.578-0.585
-// at 768, 0.588 at 192, 0.655 at 128 (tools/gpu_splitk_ab.sh); WN18 sizes 1.128 against 1.166.  `wide`: 512 after all --
-// with FB15k's 1,345 relations the slab reduce of the relation weights' gradients (6.7 M floats) leads the GEMM on the
-// side stream, and the GEMM has to be short: 0.645 ms per step against 0.680.  The rule reads the model's dimensions
-// only, one figure for every form of the layer: the split decides the summation order of dW_self, and the forms are
-// held bitwise equal to each other.
-static int auto_split_k(int M, int N, int K, bool wide = false) {
+// target: workgroups of a split-K launch.  Since the dW_self GEMM runs beside the dH GEMM (the backward layer's pairing)
+// FEWER workgroups pay in the step -- headline 0.555-0.562 ms per step at 256, 0.558-0.568 at 384, 0.565-0.568 at 448,
+// 0.567-0.575 at 512 -- but cost the GEMM itself (alone on the chip 54.6 us at 256, 51 at 448, 48.7 at 512: one workgroup
+// per CU).  The headline shape keeps 512 (the step's gain is ~1 %, inside the box-to-box spread; RGCN_SPLITK_TARGET=256
+// takes it); `narrow` -- 256 -- where the step gains 3-5 %: K >= 32,768 rows (WN18 sizes: 1.128 ms against 1.166) and the
+// basis kind (B = 2: 1.64 against 1.72).  tools/gpu_splitk_ab.sh, tools/gpu_splitk_excl.sh.  The rule reads the model's
+// dimensions only, one figure for every form of the layer: the split decides the summation order of dW_self, and the forms
+// are held bitwise equal to each other.
+static int auto_split_k(int M, int N, int K, bool narrow = false) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   if (tiles >= 192) return 1;
   static const int target_env = getenv("RGCN_SPLITK_TARGET") ? atoi(getenv("RGCN_SPLITK_TARGET")) : 0;
-  const int target = target_env > 0 ? target_env : (wide ? 512 : 256);
+  const int target = target_env > 0 ? target_env : (narrow ? 256 : 512);
   int s = (target + tiles - 1) / tiles;
   const int max_by_k = (K + 127) / 128;   // at least 128 of K per slab
   if (s > max_by_k) s = max_by_k;
@@ -706,8 +707,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   const int rows = hi - lo;
   LayerBufs& lb = c->layers[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
-  // (see auto_split_k: a long slab reduce of the relation weights' gradients in front of the dW_self GEMM)
-  const bool wide_dw = c->kind == RGCN_KIND_BLOCK && (double)2 * c->R * c->d * (c->d / c->nb) > 4e6;
+  const bool narrow_dw = c->kind == RGCN_KIND_BASIS || rows >= 32768;       // (see auto_split_k)
   static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
 
   // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
@@ -760,7 +760,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       {
         StreamScope side(c, 1);
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                         c->self_buf + (size_t)lo * d, d, 1));
@@ -793,7 +793,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
         StreamScope side(c, 1, 1);
         if (serial) RGCN_TRY(block_dw_reduce(c, l));
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                         c->self_buf + (size_t)lo * d, d, 1));
@@ -803,7 +803,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       {
         StreamScope side(c, 1);
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
       }
     }
     c->use_aux = aux_saved;
@@ -823,7 +823,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
     }
     GemmEpilogue e;
     e.mode = 2;
@@ -847,7 +847,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     if (sched == 0) {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
     }
     // G = dS . W_self^T
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
@@ -855,7 +855,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     if (sched == 2) {   // dW_self = H_in^T . dS on side stream 1, queued behind the dH GEMM
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
     }
     if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
     a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
@@ -865,7 +865,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
     if (sched == 1)
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
   } else {
     const int zc = 2 * c->B * d;
     // The four dense contractions of the layer depend on D_l / dS_l only.  Two of them -- the weight gradients dW_self =
@@ -876,7 +876,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     {
       StreamScope side(c, corun_env ? 1 : -1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, wide_dw)));
+                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
       // dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
       RGCN_TRY(wait_gather(c));            // D_l of every row
       RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
