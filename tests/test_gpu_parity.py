@@ -676,6 +676,34 @@ def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, h
     assert np.isfinite(fa[2]).all() and (E == 0 or np.abs(fg["W_f1"]).max() > 0)
 
 
+def test_bias_gradient_from_the_row_kernel_is_the_same_in_every_engine(native):
+    """db_emb comes from column partials the bottom layer's row-gradient kernel leaves behind (block_rows.hip): every
+    workgroup sums the rows IT writes, so which workgroup takes which row must not depend on anything that differs from
+    run to run -- the long rows are taken by vertex id from the tail of row_order, not in the order their threads
+    registered them (an atomic counter).  Four engines on a graph with dozens of long rows: bit-identical gradients; and
+    db_emb equals the column sums of dW_emb (float64) to 2e-6 of scale."""
+    V, R, d, nb, E = 3000, 11, 500, 100, 30000
+    params, triples, masks, dcodes = make_case(V, R, d, 2, "block", nb, E, seed=9)
+    rng = np.random.RandomState(3)
+    for h in range(40):                             # forty rows with 100 .. 400 slots
+        idx = rng.choice(E, size=rng.randint(100, 400), replace=False)
+        triples[idx, 2 if h % 2 == 0 else 0] = 7 * h
+    outs = []
+    for rep in range(4):
+        with native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=E) as eng:
+            eng.set_params(params)
+            eng.set_graph(triples)
+            eng.forward(train=True, seed=2)
+            eng.backward(dcodes)
+            outs.append(eng.get_grads())
+    for g in outs[1:]:
+        for k in outs[0]:
+            np.testing.assert_array_equal(g[k], outs[0][k], err_msg=k)
+    want = outs[0]["W_emb"].astype(np.float64).sum(axis=0)
+    scale = np.abs(outs[0]["W_emb"]).astype(np.float64).sum(axis=0).max()
+    assert np.abs(outs[0]["b_emb"] - want).max() <= 2e-6 * scale
+
+
 def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
     """mode 2 on a graph with giant rows (more than 65,536 messages, a 6,000-slot hub: the piece-by-piece order of the
     giant-row cut) still equals mode 0 bitwise in the forward pass and the gradients; a relation count whose weight
