@@ -755,17 +755,19 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // per step against 0.560-0.566 with it in front of the GEMMs on the main stream; joined a layer later: 0.563-0.568
     // (tools/gpu_env_ab.sh).  Captured steps keep the chain + GEMM pairing.
     static const int late_dw_env = getenv("RGCN_BWD_LATE_DW") ? atoi(getenv("RGCN_BWD_LATE_DW")) : 1;
-    const bool late_dw = late_dw_env != 0 && corun && serial && aux_saved && !c->capturing && rows_layer(c);
+    static const int cap_forks_bits = getenv("RGCN_CAPTURE_FORKS") ? atoi(getenv("RGCN_CAPTURE_FORKS")) : 1;
+    const bool late_dw = late_dw_env != 0 && corun && serial && rows_layer(c) &&
+                         (c->capturing ? (cap_fork && (cap_forks_bits & 4) != 0) : aux_saved);
     if (late_dw) {
       {
-        StreamScope side(c, 1);
+        StreamScope side(c, 1, 1);
         RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                           lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
       }
       RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                         c->self_buf + (size_t)lo * d, d, 1));
       {
-        StreamScope side(c, 0);
+        StreamScope side(c, 0, 4);
         RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
         RGCN_TRY(block_dw_reduce(c, l));
       }
