@@ -775,44 +775,47 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(stream_join(c, 0));
       c->dw_pending = false;
     } else {
-    if (serial) c->use_aux = false;
-    {
-      StreamScope side(c, 0);
-      RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
-      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-      if (!(corun && serial)) RGCN_TRY(block_dw_reduce(c, l));     // (behind its producer, on whichever stream that is)
-      c->dw_pending = side.active;
-    }
-    if (corun) {
-      // MFMA beside MFMA is the pairing that pays: dW_self = H^T.dS is forked to side stream 1 BEFORE dH = dS.W^T is
-      // launched, so the second GEMM fills the CU slots the first leaves idle (456 workgroups on 512) and its tail; the
-      // slab reduce of the relation-weight gradients (small, latency-bound) leads that side stream and runs under the
-      // dH GEMM's start.  0.566-0.574 ms per step against 0.580-0.587 with only the GEMMs paired and 0.597-0.599 with
-      // everything one behind the other (tools/gpu_corun_ab.sh); the message-gradient kernel itself beside the GEMMs
-      // (either end of the side stream) loses 8-10 us again.
+      struct AuxRestore {           // (an early error return must not leave the side streams switched off)
+        rgcn_ctx* c; bool v;
+        ~AuxRestore() { c->use_aux = v; }
+      } restore{c, aux_saved};
+      if (serial) c->use_aux = false;
+      {
+        StreamScope side(c, 0);
+        RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
+        RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
+        if (!(corun && serial)) RGCN_TRY(block_dw_reduce(c, l));     // (behind its producer, on whichever stream that is)
+        c->dw_pending = side.active;
+      }
+      if (corun) {
+        // MFMA beside MFMA is the pairing that pays: dW_self = H^T.dS is forked to side stream 1 BEFORE dH = dS.W^T is
+        // launched, so the second GEMM fills the CU slots the first leaves idle (456 workgroups on 512) and its tail; the
+        // slab reduce of the relation-weight gradients (small, latency-bound) leads that side stream and runs under the
+        // dH GEMM's start.  0.566-0.574 ms per step against 0.580-0.587 with only the GEMMs paired and 0.597-0.599 with
+        // everything one behind the other (tools/gpu_corun_ab.sh); the message-gradient kernel itself beside the GEMMs
+        // (either end of the side stream) loses 8-10 us again.
+        c->use_aux = aux_saved;
+        {
+          StreamScope side(c, 1, 1);
+          if (serial) RGCN_TRY(block_dw_reduce(c, l));
+          RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                            lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
+        }
+        RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                          c->self_buf + (size_t)lo * d, d, 1));
+      } else {
+        RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                          c->self_buf + (size_t)lo * d, d, 1));
+        {
+          StreamScope side(c, 1);
+          RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                            lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
+        }
+      }
       c->use_aux = aux_saved;
-      {
-        StreamScope side(c, 1, 1);
-        if (serial) RGCN_TRY(block_dw_reduce(c, l));
-        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-      }
-      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                        c->self_buf + (size_t)lo * d, d, 1));
-    } else {
-      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                        c->self_buf + (size_t)lo * d, d, 1));
-      {
-        StreamScope side(c, 1);
-        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-      }
+      RGCN_TRY(wait_gather(c));
+      RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
     }
-    c->use_aux = aux_saved;
-    RGCN_TRY(wait_gather(c));
-    RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
-    }
-
   } else if (fused_layer(c)) {
     // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
     // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
