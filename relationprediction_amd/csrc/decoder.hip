@@ -487,35 +487,30 @@ __device__ __forceinline__ void line_range(const EntArgs& a, const float* __rest
   for (int base = 0; base < n; base += 8) {
     const uint32_t co = oth, cr = rel;
     const float cg = gg;
-    constexpr int BLK = 8;
+    float4 u[8], w[8];
+    float gt[8];
 #pragma unroll
-    for (int h = 0; h < 8; h += BLK) {
-      float4 u[BLK], w[BLK];
-      float gt[BLK];
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t ot = (uint32_t)__shfl((int)co, g * 8 + t, 64) * (kLine * 4);
+      const uint32_t rt = (uint32_t)__shfl((int)cr, g * 8 + t, 64) * (kLine * 4);
+      gt[t] = __shfl(cg, g * 8 + t, 64);
+      u[t] = *reinterpret_cast<const float4*>(cbb + (ot + cb16));
+      if constexpr (RLDS) w[t] = *reinterpret_cast<const float4*>(rl + (rt + cb16));
+      else w[t] = *reinterpret_cast<const float4*>(rbb + (rt + cb16));
+    }
+    oth = 0; rel = 0; gg = 0.f;
+    if (base + 8 + cl < n) {
+      const int s = s0 + (base + 8 + cl) * step;
+      // (raw indices: nothing may consume the loaded values before the next block's shuffles, or the wait for them --
+      // and, the memory counter retiring in order, for this block's lines -- lands here)
+      oth = (uint32_t)a.e_other[s]; rel = (uint32_t)a.e_rel[s]; gg = e_g[s];
+    }
 #pragma unroll
-      for (int t = 0; t < BLK; ++t) {
-        const uint32_t ot = (uint32_t)__shfl((int)co, g * 8 + h + t, 64) * (kLine * 4), rt = (uint32_t)__shfl((int)cr, g * 8 + h + t, 64) * (kLine * 4);
-        gt[t] = __shfl(cg, g * 8 + h + t, 64);
-        u[t] = *reinterpret_cast<const float4*>(cbb + (ot + cb16));
-        if constexpr (RLDS) w[t] = *reinterpret_cast<const float4*>(rl + (rt + cb16));
-        else w[t] = *reinterpret_cast<const float4*>(rbb + (rt + cb16));
-      }
-      if (h + BLK == 8) {
-        oth = 0; rel = 0; gg = 0.f;
-        if (base + 8 + cl < n) {
-          const int s = s0 + (base + 8 + cl) * step;
-          // (raw indices: nothing may consume the loaded values before the next block's shuffles, or the wait for them
-          // -- and, the memory counter retiring in order, for this block's lines -- lands here)
-          oth = (uint32_t)a.e_other[s]; rel = (uint32_t)a.e_rel[s]; gg = e_g[s];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < BLK; ++t) {
-        acc[0] = fmaf(gt[t] * u[t].x, w[t].x, acc[0]);
-        acc[1] = fmaf(gt[t] * u[t].y, w[t].y, acc[1]);
-        acc[2] = fmaf(gt[t] * u[t].z, w[t].z, acc[2]);
-        acc[3] = fmaf(gt[t] * u[t].w, w[t].w, acc[3]);
-      }
+    for (int t = 0; t < 8; ++t) {
+      acc[0] = fmaf(gt[t] * u[t].x, w[t].x, acc[0]);
+      acc[1] = fmaf(gt[t] * u[t].y, w[t].y, acc[1]);
+      acc[2] = fmaf(gt[t] * u[t].z, w[t].z, acc[2]);
+      acc[3] = fmaf(gt[t] * u[t].w, w[t].w, acc[3]);
     }
   }
 }
@@ -1030,7 +1025,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     a.dcodes_drop = (dcodes_drop != nullptr && drop != nullptr && drop->mode != DROP_NONE) ? dcodes_drop : nullptr;
     if (drop != nullptr) a.drop = *drop; else a.drop = DropSpec{DROP_NONE, 0, 0, 1.0f, 0, nullptr, nullptr};
     // line form (default when the rows are float4-addressable): RGCN_DEC_LINES=0 selects the full-row kernel, whose
-    // sums it reproduces bit for bit (tests/test_gpu_decoder.py::test_entity_gradient_forms_are_bitwise_equal)
+    // sums it reproduces bit for bit (tests/test_gpu_train_step.py::test_entity_gradient_forms_are_bitwise_equal)
     const char* lines_env = getenv("RGCN_DEC_LINES");
     const bool lines = vec4 && !(lines_env && atoi(lines_env) == 0) && (int64_t)V * kLine * 4 < (1ll << 32);
     if (lines) {
@@ -1058,23 +1053,23 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
       if (rlds) hipLaunchKernelGGL((k_dec_entity_lines<true>), grid, block, lds, c->stream, a, b);
       else hipLaunchKernelGGL((k_dec_entity_lines<false>), grid, block, 0, c->stream, a, b);
     } else {
-    const int nvec = vec4 ? d / 4 : d;
-    const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
-    const int rpb = kEntThreads / tpr;
-    int64_t want = 2 * (int64_t)N / 2048;
-    // (sized for 1024-thread workgroups; four times as many of the 256-thread ones walk the long-row pieces)
-    const int nlb = 4 * (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
-    dim3 grid(nlb + (V + rpb - 1) / rpb), block(kEntThreads);
-    // design: two row gathers per incidence (2N incidences) + the row written; compulsory: codes and relation rows
-    // once, the incidence lists and per-triple gradients once, dL/dcodes written once
-    ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d,
-                 4.0 * d * (2.0 * V + R) + 32.0 * N);
+      const int nvec = vec4 ? d / 4 : d;
+      const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
+      const int rpb = kEntThreads / tpr;
+      int64_t want = 2 * (int64_t)N / 2048;
+      // (sized for 1024-thread workgroups; four times as many of the 256-thread ones walk the long-row pieces)
+      const int nlb = 4 * (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
+      dim3 grid(nlb + (V + rpb - 1) / rpb), block(kEntThreads);
+      // design: two row gathers per incidence (2N incidences) + the row written; compulsory: codes and relation rows
+      // once, the incidence lists and per-triple gradients once, dL/dcodes written once
+      ProfScope ps(c, "dec_entity_grad", 16.0 * N * d + 8.0 * V * d, 6.0 * N * d,
+                   4.0 * d * (2.0 * V + R) + 32.0 * N);
 #define RGCN_LAUNCH_EG(VEC, TPR) hipLaunchKernelGGL((k_dec_entity_grad<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
-    if (vec4) {
-      if (tpr == 64) RGCN_LAUNCH_EG(4, 64); else if (tpr == 128) RGCN_LAUNCH_EG(4, 128); else RGCN_LAUNCH_EG(4, 256);
-    } else {
-      if (tpr == 64) RGCN_LAUNCH_EG(1, 64); else if (tpr == 128) RGCN_LAUNCH_EG(1, 128); else RGCN_LAUNCH_EG(1, 256);
-    }
+      if (vec4) {
+        if (tpr == 64) RGCN_LAUNCH_EG(4, 64); else if (tpr == 128) RGCN_LAUNCH_EG(4, 128); else RGCN_LAUNCH_EG(4, 256);
+      } else {
+        if (tpr == 64) RGCN_LAUNCH_EG(1, 64); else if (tpr == 128) RGCN_LAUNCH_EG(1, 128); else RGCN_LAUNCH_EG(1, 256);
+      }
 #undef RGCN_LAUNCH_EG
     }
     if (vec4) hipLaunchKernelGGL((k_dec_long_finish<4>), dim3(128), dim3(256), 0, c->stream, a);
