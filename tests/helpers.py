@@ -31,6 +31,8 @@ GOLDEN_CASES = {
     "toy_block_small": ("toy_train", 16, 9, 10, 2, "block", 2, 13),
     "fb237_block_L2": ("fb237_minibatch", 14541, 237, 500, 2, "block", 100, 21),
     "fb237_basis_B2_L2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 2, 22),
+    # settings/gcn_basis.exp:5's own basis count (no stored probes: compared with the oracle directly)
+    "fb237_basis_B5_L2": ("fb237_minibatch", 14541, 237, 500, 2, "basis", 5, 23),
 }
 
 
@@ -323,6 +325,137 @@ def chunked_block_encoder_backward_float64(params, triples, V, L, acts, dcodes, 
                     dHin += dh
         grads["W_f%d" % l] = gW["f"].reshape(W_f.shape)
         grads["W_b%d" % l] = gW["b"].reshape(W_b.shape)
+        grads["b%d" % l] = np.zeros(Hin.shape[1])
+        dH = dHin
+    g0 = dH * (acts[0] > 0)
+    grads["W_emb"] = g0
+    grads["b_emb"] = g0.sum(axis=0)
+    return grads
+
+
+# ----------------------------------------------------------------------------- chunked float64 encoder (basis kind)
+def _chunked_basis_messages(H, W, C, rows_in, rel, rows_out, nrm, V, chunk, absolute=False):
+    """sum over the messages e of  nrm[e] * sum_b C[rel[e], b] * (H[rows_in[e]] . W[:, b, :])  scattered to rows_out[e]
+    ([V, d], float64), edge chunk by edge chunk in the REFERENCE's dataflow (gcn_basis.py:39-68: transform every edge's
+    endpoint row with the [d, B.d] basis tensor, scale the [chunk, B, d] terms by the gathered coefficients, sum over
+    the bases, then the sparse [V, chunk] x [chunk, d] product of gcn_basis.py:74-88) -- deliberately NOT the engine's
+    aggregate-first form.  absolute = True sums |terms| instead (the per-element error scale of the same sum)."""
+    import scipy.sparse as sp
+    from concurrent.futures import ThreadPoolExecutor
+    d_in, B, d_out = W.shape
+    W2 = (np.abs(W) if absolute else W).reshape(d_in, B * d_out)
+    Cx = np.abs(C) if absolute else C
+    Hx = np.abs(H) if absolute else H
+    E = len(rel)
+
+    def one(lo):
+        sl = slice(lo, lo + chunk)
+        n = len(rel[sl])
+        terms = (Hx[rows_in[sl]] @ W2).reshape(n, B, d_out)                     # gcn_basis.py:54-56,60-68
+        m = np.einsum("ebk,eb->ek", terms, Cx[rel[sl]])                         # :43-44
+        A = sp.coo_matrix((nrm[sl], (rows_out[sl], np.arange(n))), shape=(V, n)).tocsr()
+        return A @ m
+
+    out = np.zeros((V, d_out))
+    with ThreadPoolExecutor(max_workers=_CHUNK_THREADS) as ex:
+        for part in ex.map(one, range(0, E, chunk)):
+            out += part
+    return out
+
+
+def chunked_basis_layer_float64(params, l, L, H, triples, V, mode="train", keep=0.8, mask=None, norm_mode=None,
+                                chunk=16384, with_scale=False, return_pre=False):
+    """ONE basis layer (message_gcn.py:49-79 around gcn_basis.py:39-88) in float64 from the given layer input.
+    with_scale: also the sum of the absolute values of the terms of every output element."""
+    norm_mode = oracle.NORM_INTENDED if norm_mode is None else norm_mode
+    s, r, o = oracle.split_graph(triples)
+    n_f = oracle.incidence_values(o, V, norm_mode).astype(np.float64)
+    n_b = oracle.incidence_values(s, V, norm_mode).astype(np.float64)
+    H = np.asarray(H, dtype=np.float64)
+    W_f, W_b = params["W_f%d" % l].astype(np.float64), params["W_b%d" % l].astype(np.float64)
+    C_f, C_b = params["C_f%d" % l].astype(np.float64), params["C_b%d" % l].astype(np.float64)
+    W_self = params["W_self%d" % l].astype(np.float64)
+    S = H @ W_self
+    drop = (np.asarray(mask, dtype=np.float64) / keep) if mode == "train" else None
+    if drop is not None:
+        S = S * drop
+    pre = (_chunked_basis_messages(H, W_f, C_f, s, r, o, n_f, V, chunk) +
+           _chunked_basis_messages(H, W_b, C_b, o, r, s, n_b, V, chunk)) + S
+    out = pre if return_pre else (np.maximum(pre, 0.0) if l < L else pre)
+    if not with_scale:
+        return out
+    sc = (_chunked_basis_messages(H, W_f, C_f, s, r, o, n_f, V, chunk, absolute=True) +
+          _chunked_basis_messages(H, W_b, C_b, o, r, s, n_b, V, chunk, absolute=True))
+    Sabs = np.abs(H) @ np.abs(W_self)
+    if drop is not None:
+        Sabs = Sabs * drop
+    return out, sc + Sabs
+
+
+def chunked_basis_encoder_forward_float64(params, triples, V, L, mode="train", keep=0.8, masks=None,
+                                          norm_mode=None, chunk=16384, with_scale=False):
+    """oracle.encoder_forward for the basis kind in float64, never holding an [E, B, d] array whole."""
+    H = np.maximum(params["W_emb"].astype(np.float64) + params["b_emb"].astype(np.float64), 0.0)
+    acts, scales = [H], [np.abs(H)]
+    for l in range(1, L + 1):
+        res = chunked_basis_layer_float64(params, l, L, H, triples, V, mode=mode, keep=keep,
+                                          mask=masks[l - 1] if mode == "train" else None, norm_mode=norm_mode,
+                                          chunk=chunk, with_scale=with_scale)
+        H = res[0] if with_scale else res
+        if with_scale:
+            scales.append(res[1])
+        acts.append(H)
+    return (acts, scales) if with_scale else acts
+
+
+def chunked_basis_encoder_backward_float64(params, triples, V, L, acts, dcodes, mode="train", keep=0.8, masks=None,
+                                           norm_mode=None, chunk=16384):
+    """oracle.encoder_backward for the basis kind (SURVEY 8a row a15 = tf.gradients of gcn_basis.py:39-88) in float64,
+    edge chunk by edge chunk in the reference's per-edge dataflow, evaluated at the given activations."""
+    import scipy.sparse as sp
+    from concurrent.futures import ThreadPoolExecutor
+    norm_mode = oracle.NORM_INTENDED if norm_mode is None else norm_mode
+    s, r, o = oracle.split_graph(triples)
+    E = len(s)
+    n_f = oracle.incidence_values(o, V, norm_mode).astype(np.float64)
+    n_b = oracle.incidence_values(s, V, norm_mode).astype(np.float64)
+    acts = [np.asarray(a, dtype=np.float64) for a in acts]
+    grads = {}
+    dH = np.asarray(dcodes, dtype=np.float64)
+    for l in range(L, 0, -1):
+        W_f, W_b = params["W_f%d" % l].astype(np.float64), params["W_b%d" % l].astype(np.float64)
+        C_f, C_b = params["C_f%d" % l].astype(np.float64), params["C_b%d" % l].astype(np.float64)
+        W_self = params["W_self%d" % l].astype(np.float64)
+        d_in, B, d_out = W_f.shape
+        R = C_f.shape[0]
+        Hin, Hout = acts[l - 1], acts[l]
+        D = dH * (Hout > 0) if l < L else dH
+        dS = D * (np.asarray(masks[l - 1], dtype=np.float64) / keep) if mode == "train" else D
+        grads["W_self%d" % l] = Hin.T @ dS
+        dHin = dS @ W_self.T
+        for tag, W, C, rows_in, rows_out, nrm in (("f", W_f, C_f, s, o, n_f), ("b", W_b, C_b, o, s, n_b)):
+            W2 = W.reshape(d_in, B * d_out)
+
+            def one(lo, W2=W2, C=C, rows_in=rows_in, rows_out=rows_out, nrm=nrm):
+                sl = slice(lo, lo + chunk)
+                n = len(r[sl])
+                g = D[rows_out[sl]] * nrm[sl, None]                              # dF[e] = n[e] D[receiver]
+                x = Hin[rows_in[sl]]
+                terms = (x @ W2).reshape(n, B, d_out)
+                gscale = np.einsum("ebk,ek->eb", terms, g)                       # d/dC[rel[e], b]
+                dc = sp.coo_matrix((np.ones(n), (r[sl], np.arange(n))), shape=(R, n)).tocsr() @ gscale
+                gterms = (C[r[sl]][:, :, None] * g[:, None, :]).reshape(n, B * d_out)
+                dw = x.T @ gterms
+                dx = gterms @ W2.T
+                return dc, dw, sp.coo_matrix((np.ones(n), (rows_in[sl], np.arange(n))), shape=(V, n)).tocsr() @ dx
+            gC, gW = np.zeros((R, B)), np.zeros((d_in, B * d_out))
+            with ThreadPoolExecutor(max_workers=_CHUNK_THREADS) as ex:
+                for dc, dw, dh in ex.map(one, range(0, E, chunk)):
+                    gC += dc
+                    gW += dw
+                    dHin += dh
+            grads["C_%s%d" % (tag, l)] = gC
+            grads["W_%s%d" % (tag, l)] = gW.reshape(W.shape)
         grads["b%d" % l] = np.zeros(Hin.shape[1])
         dH = dHin
     g0 = dH * (acts[0] > 0)

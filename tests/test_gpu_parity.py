@@ -69,6 +69,8 @@ def gate_aware_gradient_check(c, acts, grads, norm, direct):
 GEMM_SHAPES = [
     (1, 1, 1), (33, 17, 5), (128, 128, 16), (129, 130, 33), (257, 500, 500), (1000, 500, 500),
     (64, 64, 4), (500, 500, 1000), (300, 77, 129),
+    # the basis kind at settings/gcn_basis.exp:5's B = 5: a 5,000-wide (2.B.d) K (forward), N (dZ) and M (dW', split-K)
+    (300, 500, 5000), (300, 5000, 500), (5000, 500, 300),
 ]
 
 
@@ -219,6 +221,8 @@ BASIS_CASES = [
     (25, 6, 12, 2, 2, 0),        # empty graph
     (30, 5, 16, 3, 9, 90),       # B > 8: two register passes
     (300, 40, 500, 2, 2, 900),   # real width d = 500, B = 2
+    (300, 40, 500, 2, 5, 900),   # settings/gcn_basis.exp:5: B = 5 at d = 500 (5,000-wide contraction)
+    (600, 9, 64, 2, 3, 200),     # most rows without a message in either direction (the row-compacted contraction)
 ]
 
 
@@ -433,6 +437,24 @@ def test_fb237_minibatch_full_parity(native):
         gate_aware_gradient_check(c, acts, grads, "intended", direct)
 
 
+def test_fb237_basis_b5_minibatch_full_parity(native):
+    """settings/gcn_basis.exp:5's own basis count at full size (BASELINE config 3 with B = 5; gcn_basis.py:60-68): the
+    real-structure 15,000-edge FB15k-237 minibatch, d = 500, two layers, train mode with injected masks -- every
+    activation within 1e-4, every gradient (W_f / W_b [500,5,500], C_f / C_b, W_self, W_emb, b_emb) against the oracle."""
+    c = helpers.golden_inputs("fb237_basis_B5_L2")
+    oacts, ograds = oracle.encoder_step(c["params"], c["triples"], c["V"], c["L"], "basis", c["dcodes"],
+                                        keep_prob=0.8, dropout_masks=c["masks"])
+    acts, grads = run_engine(native, c["V"], c["R"], c["d"], c["L"], "basis", c["nb"], c["params"],
+                             c["triples"], c["masks"], c["dcodes"])
+    assert set(grads) - {"W_relation"} == set(ograds) - {"W_relation"}
+    try:
+        compare(acts, grads, oacts, ograds, tag="fb237-basis-b5")
+    except AssertionError as direct:
+        if "grad" not in str(direct):
+            raise
+        gate_aware_gradient_check(c, acts, grads, "intended", direct)
+
+
 def test_full_graph_inference_shape(native):
     """Full-graph scoring shape (code/model.py:59-81): all 38,001 real FB15k-237 valid+test triples, test mode."""
     c = helpers.golden_inputs("fb237_block_L2")
@@ -492,6 +514,7 @@ F64_CASES = {
     "block_d500": lambda: _made_case(257, 6, 500, 2, "block", 100, 4000, 5),
     "fb237_block_L2": lambda: helpers.golden_inputs("fb237_block_L2"),
     "fb237_basis_B2_L2": lambda: helpers.golden_inputs("fb237_basis_B2_L2"),
+    "fb237_basis_B5_L2": lambda: helpers.golden_inputs("fb237_basis_B5_L2"),
 }
 
 
@@ -814,38 +837,43 @@ def test_training_graph_scale_properties(native):
         assert float(np.abs(grads[2][k] - lin).max()) <= 2e-5 * sc, (k, float(np.abs(grads[2][k] - lin).max()), sc)
 
 
-def test_training_graph_elementwise_parity(native):
-    """ELEMENT-WISE parity at BASELINE's largest single-GPU graph: the 272,115-edge FB15k-237 training-graph shape
-    (V = 14,541, d = 500, 100 blocks, 2 layers; 5,000+ rows on the long-row path, one row beyond the 2,048-slot giant-row
-    cut) against the edge-chunked float64 restatement of the oracle (tests/helpers.py, pinned to oracle.encoder_step on
-    the CPU by tests/test_oracle_chunked.py).  Reference: gcn_basis_concat.py:35-83, message_gcn.py:49-79,
-    model.py:59-81 (the evaluation encode is the test-mode forward pass of this graph).
-
-      * forward in test mode (= the evaluation encode) AND in train mode (the device's own dropout draw, read back):
-        every element of every layer within 1e-4 absolute of the chained float64 forward (north_star's tolerance);
-      * layer by layer from the ENGINE's own layer input: every element within 1e-5 of ITS error scale (the sum of the
-        absolute values of its terms) -- tight enough that ONE message of the giant row delivered to a neighbouring
-        vertex fails it, which the test demonstrates on a corrupted reference;
-      * every gradient of the train-mode pass against the float64 reverse mode at the engine's own activations
-        (no gate can differ): every entry within 5e-6 of its tensor's scale, 2e-6 in l2."""
+def _bench_module():
     import importlib.util
-    import os
-    from helpers import (chunked_block_encoder_forward_float64, chunked_block_encoder_backward_float64,
-                         chunked_block_layer_float64, error_against)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("bench_for_graph3", os.path.join(root, "bench.py"))
+    spec = importlib.util.spec_from_file_location("bench_for_graphs", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    triples = bench.load_graph("synth:fb237_valid_test:272115")
-    V, R, d, nb, L, E = 14541, 237, 500, 100, 2, len(triples)
+    return bench
+
+
+def _elementwise_parity_at_scale(native, triples, V, R, kind, nb, seed, want_giant=False, gradients=True,
+                                 misplaced_message_demo=False):
+    """ELEMENT-WISE parity of the 2-layer d = 500 encoder on a graph too large for the numpy oracle's [E, ...] gathers,
+    against the edge-chunked float64 restatements of tests/helpers.py (pinned to oracle.encoder_step on the CPU by
+    tests/test_oracle_chunked.py):
+
+      * forward in test mode (= the evaluation encode, model.py:59-81) AND in train mode (the device's own dropout draw,
+        read back): every element of every layer within 1e-4 absolute of the chained float64 forward (north_star);
+      * layer by layer from the ENGINE's own layer input: every element within 1e-5 of ITS error scale (the sum of the
+        absolute values of its terms);
+      * every gradient of the train-mode pass against the float64 reverse mode at the engine's own activations
+        (no gate can differ): every entry within 5e-6 of its tensor's scale, 2e-6 in l2."""
+    from helpers import error_against
+    import helpers as hp
+    layer64 = hp.chunked_block_layer_float64 if kind == "block" else hp.chunked_basis_layer_float64
+    fwd64 = hp.chunked_block_encoder_forward_float64 if kind == "block" else hp.chunked_basis_encoder_forward_float64
+    bwd64 = hp.chunked_block_encoder_backward_float64 if kind == "block" else hp.chunked_basis_encoder_backward_float64
+    d, L, E = 500, 2, len(triples)
     s, r, o = oracle.split_graph(triples)
     slots = np.bincount(o, minlength=V) + np.bincount(s, minlength=V)
-    assert slots.max() > 2048 and (slots > 32).sum() > 1000            # the giant-row and long-row paths are in play
-    rng = np.random.RandomState(17)
-    params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
+    assert (slots > 32).sum() > 1000                                   # the long-row path is in play
+    if want_giant:
+        assert slots.max() > 2048                                      # ... and the giant-row cut
+    rng = np.random.RandomState(seed)
+    params = oracle.init_params(V, R, d, L, kind, nb, rng=rng)
     params["b_emb"] = (rng.randn(d) * 0.01).astype(np.float32)
     dcodes = (rng.randn(V, d) * 0.01).astype(np.float32)
-    with native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E) as eng:
+    with native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, max_edges=E) as eng:
         eng.set_params(params)
         eng.set_graph(triples)
         eng.forward(train=False)
@@ -853,49 +881,83 @@ def test_training_graph_elementwise_parity(native):
         eng.forward(train=True, seed=5)
         acts_train = [eng.activation(l) for l in range(L + 1)]
         masks = [eng.dropout_mask(l) for l in range(1, L + 1)]
-        eng.backward(dcodes)
-        grads = {k: v for k, v in eng.get_grads().items() if v is not None}
+        if gradients:
+            eng.backward(dcodes)
+            grads = {k: v for k, v in eng.get_grads().items() if v is not None}
     assert 0.78 < float(masks[0].mean()) < 0.82
 
-    def layerwise(acts, mode):
-        worst = 0.0
-        for l in range(1, L + 1):
-            ref, sc = chunked_block_layer_float64(params, l, L, acts[l - 1], triples, V, mode=mode,
-                                                  mask=masks[l - 1] if mode == "train" else None, with_scale=True)
-            ratio = np.abs(acts[l].astype(np.float64) - ref) / (sc + 1e-30)
-            worst = max(worst, float(ratio.max()))
-            assert worst <= 1e-5, (mode, l, worst, np.unravel_index(int(ratio.argmax()), ratio.shape))
-        return worst
-
     for mode, acts in (("test", acts_test), ("train", acts_train)):
-        chained = chunked_block_encoder_forward_float64(params, triples, V, L, mode=mode, masks=masks)
+        chained = fwd64(params, triples, V, L, mode=mode, masks=masks)
         for l in range(L + 1):
             err = float(np.abs(acts[l].astype(np.float64) - chained[l]).max())
             assert err <= 1e-4, (mode, l, err)
-        layerwise(acts, mode)
+        for l in range(1, L + 1):
+            ref, sc = layer64(params, l, L, acts[l - 1], triples, V, mode=mode,
+                              mask=masks[l - 1] if mode == "train" else None, with_scale=True)
+            ratio = np.abs(acts[l].astype(np.float64) - ref) / (sc + 1e-30)
+            assert float(ratio.max()) <= 1e-5, (mode, l, float(ratio.max()),
+                                                np.unravel_index(int(ratio.argmax()), ratio.shape))
 
-    # ---- the check above SEES one misplaced message of the giant row: take one forward message into the giant row
-    # out of the layer-1 reference and hand it to the next vertex; the engine's (correct) output must then fail
-    vg = int(slots.argmax())
-    e = int(np.flatnonzero(o == vg)[0])
-    H0 = acts_test[0].astype(np.float64)
-    pre, sc = chunked_block_layer_float64(params, 1, L, H0, triples, V, mode="test", with_scale=True, return_pre=True)
-    n_f = float(oracle.incidence_values(o, V, oracle.NORM_INTENDED)[e])
-    m = n_f * np.einsum("bij,bj->bi", params["W_f1"][r[e]].astype(np.float64),
-                        H0[s[e]].reshape(nb, d // nb)).reshape(d)
-    wrong = pre.copy()
-    wrong[vg] -= m
-    wrong[(vg + 1) % V] += m
-    got = acts_test[1].astype(np.float64)
-    for row in (vg, (vg + 1) % V):
-        ok = np.abs(got[row] - np.maximum(pre[row], 0.0)) / (sc[row] + 1e-30)
-        bad = np.abs(got[row] - np.maximum(wrong[row], 0.0)) / (sc[row] + 1e-30)
-        assert float(ok.max()) <= 1e-5 < float(bad.max()), (row, float(ok.max()), float(bad.max()))
+    if misplaced_message_demo:
+        # the check above SEES one misplaced message of the row with the most slots: take one forward message into it
+        # out of the layer-1 reference and hand it to the next vertex; the engine's (correct) output must then fail
+        assert kind == "block"
+        vg = int(slots.argmax())
+        e = int(np.flatnonzero(o == vg)[0])
+        H0 = acts_test[0].astype(np.float64)
+        pre, sc = layer64(params, 1, L, H0, triples, V, mode="test", with_scale=True, return_pre=True)
+        n_f = float(oracle.incidence_values(o, V, oracle.NORM_INTENDED)[e])
+        m = n_f * np.einsum("bij,bj->bi", params["W_f1"][r[e]].astype(np.float64),
+                            H0[s[e]].reshape(nb, d // nb)).reshape(d)
+        wrong = pre.copy()
+        wrong[vg] -= m
+        wrong[(vg + 1) % V] += m
+        got = acts_test[1].astype(np.float64)
+        for row in (vg, (vg + 1) % V):
+            ok = np.abs(got[row] - np.maximum(pre[row], 0.0)) / (sc[row] + 1e-30)
+            bad = np.abs(got[row] - np.maximum(wrong[row], 0.0)) / (sc[row] + 1e-30)
+            assert float(ok.max()) <= 1e-5 < float(bad.max()), (row, float(ok.max()), float(bad.max()))
 
-    # ---- every gradient, float64 reverse mode at the engine's own activations
-    g64 = chunked_block_encoder_backward_float64(params, triples, V, L, acts_train, dcodes, mode="train", masks=masks)
-    for k, g in grads.items():
-        if k not in g64 or k.startswith("b") and k != "b_emb":
-            continue
-        emax, el2 = error_against(g64[k], g)
-        assert emax <= 5e-6 and el2 <= 2e-6, (k, emax, el2)
+    if gradients:
+        g64 = bwd64(params, triples, V, L, acts_train, dcodes, mode="train", masks=masks)
+        checked = 0
+        for k, g in grads.items():
+            if k not in g64 or k.startswith("b") and k != "b_emb":
+                continue
+            emax, el2 = error_against(g64[k], g)
+            assert emax <= 5e-6 and el2 <= 2e-6, (k, emax, el2)
+            checked += 1
+        assert checked >= (7 if kind == "block" else 11)
+
+
+def test_training_graph_elementwise_parity(native):
+    """BASELINE's largest single-GPU graph, block kind: the 272,115-edge FB15k-237 training-graph shape (V = 14,541,
+    100 blocks; 5,000+ rows on the long-row path, one row beyond the 2,048-slot giant-row cut), with the demonstration
+    that ONE message of the giant row handed to the neighbouring vertex fails the check.  Reference:
+    gcn_basis_concat.py:35-83, message_gcn.py:49-79, model.py:59-81."""
+    triples = _bench_module().load_graph("synth:fb237_valid_test:272115")
+    _elementwise_parity_at_scale(native, triples, 14541, 237, "block", 100, 17, want_giant=True,
+                                 misplaced_message_demo=True)
+
+
+def test_training_graph_elementwise_parity_basis(native):
+    """The same graph through the BASIS kind (BASELINE config 3's evaluation encode and full-graph train pass, B = 2):
+    the aggregate-first kernels' long-row path at 5,000+ rows and a 2,397-slot hub, against the float64 restatement of
+    the reference's PER-EDGE dataflow (gcn_basis.py:39-88).  Every gradient incl. C_f / C_b of both layers."""
+    triples = _bench_module().load_graph("synth:fb237_valid_test:272115")
+    _elementwise_parity_at_scale(native, triples, 14541, 237, "basis", 2, 18, want_giant=True)
+
+
+def test_wn18_training_graph_elementwise_parity(native):
+    """BASELINE config 4 at SURVEY 8d's size on one GPU: WN18 (V 40,943, R 18), the 141,442-edge training-graph shape
+    drawn from the real valid+test histograms (three relations hold 73 % of the edges: relation chunks thousands of
+    messages long), block kind.  Evaluation encode, train-mode forward and every gradient."""
+    triples = _bench_module().load_graph("synth:wn18_valid_test:141442")
+    _elementwise_parity_at_scale(native, triples, 40943, 18, "block", 100, 19)
+
+
+def test_fb15k_training_graph_evaluation_encode(native):
+    """BASELINE config 5's evaluation encode on one GPU: FB15k (V 14,951, R 1,345), the 483,142-edge training-graph
+    shape drawn from the real valid histograms, block kind: test-mode and train-mode forward, element-wise."""
+    triples = _bench_module().load_graph("synth:fb15k_minibatch:483142")
+    _elementwise_parity_at_scale(native, triples, 14951, 1345, "block", 100, 20, gradients=False)

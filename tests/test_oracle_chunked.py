@@ -46,3 +46,29 @@ def test_chunked_float64_block_encoder_is_the_oracle():
                 assert (np.abs(b) <= sc * (1 + 1e-12) + 1e-300).all()      # the scale bounds the value it belongs to
             for k, ref in grads.items():
                 assert np.abs(gg[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), k
+
+
+def test_chunked_float64_basis_encoder_is_the_oracle():
+    """The edge-chunked float64 restatement of the BASIS encoder (tests/helpers.py: what the 272,115-edge basis GPU test
+    compares with; reference dataflow of gcn_basis.py:39-88, per edge) is oracle.encoder_step on a case both can run --
+    every norm reading, train and test mode, B = 1 and B = 3, chunks that cut rows and relations anywhere."""
+    from helpers import (chunked_basis_encoder_forward_float64, chunked_basis_encoder_backward_float64, make_case,
+                         oracle_float64)
+    for B, seed in ((3, 6), (1, 7)):
+        params, triples, masks, dcodes = make_case(50, 7, 12, 2, "basis", B, 333, seed=seed)
+        for norm in (oracle.NORM_INTENDED, oracle.NORM_TF_AS_EXECUTED, oracle.NORM_NONE):
+            for mode in ("train", "test"):
+                with oracle_float64():
+                    p64 = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
+                    acts, grads = oracle.encoder_step(p64, triples, 50, 2, "basis", dcodes.astype(np.float64),
+                                                      keep_prob=0.8, dropout_masks=masks, norm_mode=norm, mode=mode)
+                    got, scales = chunked_basis_encoder_forward_float64(params, triples, 50, 2, mode=mode, masks=masks,
+                                                                        norm_mode=norm, chunk=37, with_scale=True)
+                    gg = chunked_basis_encoder_backward_float64(params, triples, 50, 2, acts, dcodes, mode=mode,
+                                                                masks=masks, norm_mode=norm, chunk=41)
+                for a, b, sc in zip(acts, got, scales):
+                    assert np.abs(a - b).max() <= 1e-12 * max(np.abs(a).max(), 1.0)
+                    assert (np.abs(b) <= sc * (1 + 1e-12) + 1e-300).all()
+                assert set(gg) == set(grads)
+                for k, ref in grads.items():
+                    assert np.abs(gg[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), (k, B, norm, mode)
