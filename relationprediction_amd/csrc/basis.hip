@@ -5,12 +5,17 @@
 // 15,000-edge graph), scale by C[type] ([E,B,d] intermediates, 150 MB), reduce over B, then the
 // [V,E] x [E,d] sparse product.  Because the coefficient is a per-edge scalar, aggregation commutes
 // with the basis contraction:
-//     Z[v,(dir,b),:] = sum_{messages m -> v of direction dir} n_m C[rel_m,b] H[src_m,:]     (HBM-bound gather)
-//     pre-activation = dropout(H.W_self) + Z . W'          ([V,2B.d] x [2B.d,d] on the fp32 MFMA GEMM)
-// so the dense work is V rows instead of E rows per direction and no [E,B,d] tensor ever exists.
-// Backward:  dZ = D . W'^T,  dW' = Z^T . D  (GEMMs),
-//     dC[rel,b]  = sum_{m: rel_m = rel} n_m <H[src_m], dZ[dst_m,dir,b,:]>          (per-relation chunks)
-//     dH[u]     += sum_{m: src_m = u} n_m sum_b C[rel_m,b] dZ[dst_m,dir,b,:]        (source-major gather,
+//     Z[(v,dir),b,:] = sum_{messages m -> v of direction dir} n_m C[rel_m,b] H[src_m,:]     (HBM-bound gather)
+//     pre-activation[v] = dropout(H.W_self)[v] + sum_dir Z[(v,dir)] . W'_dir     ([units, B.d] x [B.d, d] on the MFMA GEMM)
+// so the dense work is done once per (row, direction) UNIT that receives a message instead of once per edge, and no
+// [E,B,d] tensor ever exists.  Like the reference, which works per edge (gcn_basis.py:39-46), nothing is computed for
+// a vertex without messages: Z, dZ and the operand of dW' are COMPACTED over the units (GraphBufs::unit_ptr /
+// unit_rows, built by the graph preparation; on the FB15k-237 minibatch 5,370 + 7,082 of 2 x 14,541), one group of the
+// batched GEMM per direction with its row count read on the device (GemmBatch).  Layout: Zc, dZc [2][V][B.d] (V = the
+// capacity of a direction), products and gathered upstream rows [2][V][d].
+// Backward:  dZ[(v,dir)] = D[v] . W'_dir^T,  dW'_dir = Zc_dir^T . D[rows of the units]  (GEMMs),
+//     dC[rel,b]  = sum_{m: rel_m = rel} n_m <H[src_m], dZ[(dst_m,dir),b,:]>        (per-relation chunks)
+//     dH[u]     += sum_{m: src_m = u} n_m sum_b C[rel_m,b] dZ[(dst_m,dir),b,:]      (source-major gather,
 //                  fused with the self-loop gradient add, relu' and the dropout-scaled copy).
 #include "rgcn_internal.h"
 
@@ -38,11 +43,14 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
 __device__ __forceinline__ float drop_scale(const DropSpec& ds, size_t idx) { return drop_factor(ds, idx); }
 
 constexpr int kRowThreads = 1024;
-constexpr int kLongBlocks = 64;    // leading workgroups of a row launch that walk the long-row list
+// leading workgroups of a row launch that walk the long-row list: 64 at minibatch scale, 512 at full-graph scale (the
+// 272,115-edge training graph has 5,000+ long rows and a 2,397-slot hub)
+inline int long_blocks(const rgcn_ctx* c) { return 2 * c->g.E > 65536 ? 512 : 64; }
 
 struct AggArgs {
   const float* Hin;          // [V,d]
-  float* Z;                  // [V, 2B*d]
+  float* Z;                  // compacted [2][V][B*d]
+  const int32_t* unit_ptr;   // [2][V+1]
   const int32_t* row_ptr;    // incidence CSR (rows = destinations)
   const int32_t* d_src;      // per slot: source vertex, directed relation, normalisation
   const int32_t* d_rel;
@@ -107,7 +115,7 @@ __device__ __forceinline__ void agg_range(const AggArgs& a, int s0, int s1, int 
 template <int VEC, int TPR>
 __global__ void __launch_bounds__(kRowThreads) k_basis_agg(AggArgs a, int n_long_blocks) {
   const int nvec = a.d / VEC;
-  const size_t zstride = (size_t)2 * a.B * a.d;
+  const size_t zstride = (size_t)a.B * a.d;
   if ((int)blockIdx.x < n_long_blocks) {
     __shared__ float red[8][128 * VEC];
     const int cl = threadIdx.x & 127, sl = threadIdx.x >> 7;
@@ -139,8 +147,11 @@ __global__ void __launch_bounds__(kRowThreads) k_basis_agg(AggArgs a, int n_long
                 for (int w = 1; w < 8; ++w) u += red[w][cl * VEC + k];
                 t[k] = u;
               }
-              const int blk = (q < BT ? 0 : a.B) + a.b0 + b;
-              vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)blk * a.d + (size_t)cidx * VEC, t);
+              const int dir = q < BT ? 0 : 1;
+              const int32_t* up = a.unit_ptr + (size_t)dir * (a.V + 1) + v;
+              const int u = up[0];
+              if (up[1] > u)
+                vstore<VEC>(a.Z + ((size_t)dir * a.V + u) * zstride + (size_t)(a.b0 + b) * a.d + (size_t)cidx * VEC, t);
             }
             __syncthreads();
           }
@@ -153,7 +164,11 @@ __global__ void __launch_bounds__(kRowThreads) k_basis_agg(AggArgs a, int n_long
   if (v >= a.V) return;
   const int lane = threadIdx.x % TPR;
   const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
-  if (end - beg > kLongRow) return;      // a long-row workgroup of this launch owns it
+  if (end == beg || end - beg > kLongRow) return;      // no unit at all / a long-row workgroup of this launch owns it
+  const int uf = a.unit_ptr[v], ub = a.unit_ptr[(size_t)a.V + 1 + v];
+  const bool has_f = a.unit_ptr[v + 1] > uf, has_b = a.unit_ptr[(size_t)a.V + 2 + v] > ub;
+  float* zf = a.Z + (size_t)uf * zstride + (size_t)a.b0 * a.d;
+  float* zb = a.Z + ((size_t)a.V + ub) * zstride + (size_t)a.b0 * a.d;
   for (int cidx = lane; cidx < nvec; cidx += TPR) {
     float accf[BT][VEC], accb[BT][VEC];
 #pragma unroll
@@ -164,14 +179,34 @@ __global__ void __launch_bounds__(kRowThreads) k_basis_agg(AggArgs a, int n_long
 #pragma unroll
     for (int b = 0; b < BT; ++b)
       if (b < a.nbt) {
-        vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)(a.b0 + b) * a.d + (size_t)cidx * VEC, accf[b]);
-        vstore<VEC>(a.Z + (size_t)v * zstride + (size_t)(a.B + a.b0 + b) * a.d + (size_t)cidx * VEC, accb[b]);
+        if (has_f) vstore<VEC>(zf + (size_t)b * a.d + (size_t)cidx * VEC, accf[b]);
+        if (has_b) vstore<VEC>(zb + (size_t)b * a.d + (size_t)cidx * VEC, accb[b]);
       }
   }
 }
 
+// Dc[dir][i][:] = D[unit_rows[dir][i]][:] for the units of both directions: the row operand of dZ = D.W'^T and the
+// K operand of dW' = Zc^T.D, compacted like Zc.  One 128-lane group per unit; groups beyond a direction's count leave.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_gather_units(const float* __restrict__ D, const int32_t* __restrict__ unit_ptr,
+                                                      const int32_t* __restrict__ unit_rows, float* __restrict__ Dc,
+                                                      int V, int d) {
+  const int i = blockIdx.x * 2 + (threadIdx.x >> 7), dir = blockIdx.y;
+  if (i >= unit_ptr[(size_t)dir * (V + 1) + V]) return;
+  const int v = unit_rows[(size_t)dir * V + i];
+  const float* src = D + (size_t)v * d;
+  float* dst = Dc + ((size_t)dir * V + i) * d;
+  for (int c = (threadIdx.x & 127) * VEC; c < d; c += 128 * VEC) {
+    float t[VEC];
+    vload<VEC>(src + c, t);
+    vstore<VEC>(dst + c, t);
+  }
+}
+
 struct BwdGatherArgs {
-  const float* dZ;           // [V, 2B*d]
+  const float* dZ;           // compacted [2][V][B*d]
+  const int32_t* unit_ptr;   // [2][V+1]
+  int32_t V;
   const int32_t* row_ptr;    // incidence CSR (rows = sources); nullptr: no relational part
   const int32_t* s_dst;      // per source-order slot: destination vertex, directed relation, normalisation
   const int32_t* s_rel;
@@ -193,8 +228,11 @@ __device__ __forceinline__ void gather_range(const BwdGatherArgs& a, int s0, int
     const float n0 = a.s_norm[s];
     const int dst1 = two ? a.s_dst[s + step] : dst0, rel1 = two ? a.s_rel[s + step] : rel0;
     const float n1 = two ? a.s_norm[s + step] : 0.f;
-    const float* z0 = a.dZ + ((size_t)dst0 * 2 * a.B + (rel0 < a.R ? 0 : a.B)) * d + (size_t)cidx * VEC;
-    const float* z1 = a.dZ + ((size_t)dst1 * 2 * a.B + (rel1 < a.R ? 0 : a.B)) * d + (size_t)cidx * VEC;
+    // the unit of (destination, direction): it exists, this very message lands there
+    const int dir0 = rel0 < a.R ? 0 : 1, dir1 = rel1 < a.R ? 0 : 1;
+    const int u0 = a.unit_ptr[(size_t)dir0 * (a.V + 1) + dst0], u1 = a.unit_ptr[(size_t)dir1 * (a.V + 1) + dst1];
+    const float* z0 = a.dZ + ((size_t)dir0 * a.V + u0) * a.B * d + (size_t)cidx * VEC;
+    const float* z1 = a.dZ + ((size_t)dir1 * a.V + u1) * a.B * d + (size_t)cidx * VEC;
     const float* c0 = a.coef + (size_t)rel0 * a.B;
     const float* c1 = a.coef + (size_t)rel1 * a.B;
     for (int b = 0; b < a.B; ++b) {
@@ -286,7 +324,9 @@ __global__ void __launch_bounds__(kRowThreads) k_basis_bwd_gather(BwdGatherArgs 
 
 struct DcoefArgs {
   const float* Hin;
-  const float* dZ;
+  const float* dZ;           // compacted [2][V][B*d]
+  const int32_t* unit_ptr;   // [2][V+1]
+  int32_t V;
   const int32_t* m_src;
   const int32_t* m_dst;
   const float* m_norm;
@@ -317,7 +357,8 @@ __global__ void __launch_bounds__(256) k_basis_dcoef(DcoefArgs a) {
   const int beg = a.rel_ptr[rel] + (bid - a.chunk_ptr[rel]) * a.chunk;
   const int end = min(beg + a.chunk, a.rel_ptr[rel + 1]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int dirb = rel < a.R ? 0 : a.B;
+  const int dir = rel < a.R ? 0 : 1;
+  const int32_t* up = a.unit_ptr + (size_t)dir * (a.V + 1);
   const int nvec = a.d / VEC;
   for (int b0 = 0; b0 < a.B; b0 += BT) {
     float part[BT];
@@ -326,7 +367,7 @@ __global__ void __launch_bounds__(256) k_basis_dcoef(DcoefArgs a) {
     for (int j = beg + wave; j < end; j += 4) {
       const float nrm = a.m_norm[j];
       const float* xp = a.Hin + (size_t)a.m_src[j] * a.d;
-      const float* zp = a.dZ + ((size_t)a.m_dst[j] * 2 * a.B + dirb + b0) * a.d;
+      const float* zp = a.dZ + (((size_t)dir * a.V + up[a.m_dst[j]]) * a.B + b0) * a.d;
       for (int cidx = lane; cidx < nvec; cidx += 64) {
         float x[VEC];
         vload<VEC>(xp + (size_t)cidx * VEC, x);
@@ -395,21 +436,24 @@ rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, fl
   AggArgs a;
   a.Hin = Hin; a.Z = Z; a.row_ptr = c->g.row_ptr; a.d_src = c->g.d_src; a.d_rel = c->g.d_rel;
   a.d_norm = c->g.d_norm; a.coef = c->layers[layer].coef; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong;
+  a.unit_ptr = c->g.unit_ptr;
   a.V = c->V; a.d = c->d; a.B = c->B; a.R = c->R;
   const bool vec4 = (c->d % 4 == 0) && aligned16(Hin) && aligned16(Z);
   const int nvec = vec4 ? c->d / 4 : c->d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
   const int rpb = kRowThreads / tpr;
-  dim3 grid(kLongBlocks + (c->V + rpb - 1) / rpb), block(kRowThreads);
+  const int nlb = long_blocks(c);
+  dim3 grid(nlb + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
   for (int b0 = 0; b0 < c->B; b0 += BT) {
     a.b0 = b0;
     a.nbt = c->B - b0 < BT ? c->B - b0 : BT;
     const double rows = M < c->V ? M : (double)c->V;     // compulsory: each gathered row of H once
-    ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + 2.0 * a.nbt * c->V) + 20.0 * M, 4.0 * M * a.nbt * c->d,
-                 4.0 * c->d * (rows + 2.0 * a.nbt * c->V) + 20.0 * M);
+    const double units = M < 2.0 * c->V ? M : 2.0 * c->V;   // (at most one unit per message)
+    ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + a.nbt * units) + 20.0 * M, 4.0 * M * a.nbt * c->d,
+                 4.0 * c->d * (rows + a.nbt * units) + 20.0 * M);
 #define RGCN_LAUNCH_AGG(VEC, TPR) \
-  hipLaunchKernelGGL((k_basis_agg<VEC, TPR>), grid, block, 0, c->stream, a, kLongBlocks)
+  hipLaunchKernelGGL((k_basis_agg<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
     if (vec4) {
       if (tpr == 64) RGCN_LAUNCH_AGG(4, 64); else if (tpr == 128) RGCN_LAUNCH_AGG(4, 128); else RGCN_LAUNCH_AGG(4, 256);
     } else {
@@ -428,18 +472,20 @@ rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const
   a.row_ptr = with_messages ? c->g.row_ptr : nullptr;
   a.s_dst = c->g.s_dst; a.s_rel = c->g.s_rel; a.s_norm = c->g.s_norm;
   a.coef = c->layers[layer].coef; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong;
+  a.unit_ptr = c->g.unit_ptr; a.V = c->V;
   a.B = c->B; a.R = c->R; a.c = ca;
   const bool vec4 = (c->d % 4 == 0) && aligned16(dZ) && aligned16(ca.out) && aligned16(ca.base) &&
                     aligned16(ca.gate) && aligned16(ca.out2);
   const int nvec = vec4 ? c->d / 4 : c->d;
   const int tpr = nvec <= 64 ? 64 : (nvec <= 128 ? 128 : 256);
   const int rpb = kRowThreads / tpr;
-  const int nlb = with_messages ? kLongBlocks : 0;
+  const int nlb = with_messages ? long_blocks(c) : 0;
   dim3 grid(nlb + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
-  // compulsory: dZ [V, 2B d] once, base / gate / out / out2 once each
+  const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
+  // compulsory: dZ of every unit once, base / gate / out / out2 once each
   ProfScope ps(c, "basis_bwd_gather", 4.0 * c->d * (M * c->B + 4.0 * c->V) + 20.0 * M, 2.0 * M * c->B * c->d,
-               4.0 * c->d * (2.0 * c->B * c->V + 4.0 * c->V) + 20.0 * M);
+               4.0 * c->d * (c->B * units + 4.0 * c->V) + 20.0 * M);
 #define RGCN_LAUNCH_BG(VEC, TPR) \
   hipLaunchKernelGGL((k_basis_bwd_gather<VEC, TPR>), grid, block, 0, c->stream, a, nlb)
   if (vec4) {
@@ -459,12 +505,14 @@ rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* d
     if ((size_t)nchunks * c->B > c->slab_dw_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: dC slab too small");
     DcoefArgs a;
     a.Hin = Hin; a.dZ = dZ; a.m_src = c->g.m_src; a.m_dst = c->g.m_dst; a.m_norm = c->g.m_norm;
+    a.unit_ptr = c->g.unit_ptr; a.V = c->V;
     a.rel_ptr = c->g.rel_ptr; a.chunk_ptr = c->g.chunk_ptr; a.slab = c->slab_dw;
     a.R = c->R; a.B = c->B; a.d = c->d; a.chunk = c->g.chunk;
     const double M = 2.0 * c->g.E / c->world;
     const double rows = M < c->V ? M : (double)c->V;
+    const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
     ProfScope ps(c, "basis_dcoef", 4.0 * c->d * M * (1.0 + c->B), 2.0 * M * c->B * c->d,
-                 4.0 * c->d * (rows + 2.0 * c->B * c->V) + 16.0 * M);
+                 4.0 * c->d * (rows + c->B * units) + 16.0 * M);
     if (c->d % 4 == 0 && aligned16(Hin) && aligned16(dZ))
       hipLaunchKernelGGL((k_basis_dcoef<4>), dim3(nchunks), dim3(256), 0, c->stream, a);
     else
@@ -478,6 +526,19 @@ rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* d
                        c->g.chunk_ptr, c->layers[layer].gcoef, R2, c->B);
     RGCN_HIP(c, hipGetLastError());
   }
+  return RGCN_OK;
+}
+
+rgcn_status basis_gather_units(rgcn_ctx* c, const float* D, float* Dc) {
+  const double M = 2.0 * c->g.E / c->world;
+  const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
+  ProfScope ps(c, "basis_gather_units", 8.0 * c->d * units + 8.0 * units, 0);
+  dim3 grid((unsigned)((c->V + 1) / 2), 2), block(256);
+  if (c->d % 4 == 0 && aligned16(D) && aligned16(Dc))
+    hipLaunchKernelGGL((k_gather_units<4>), grid, block, 0, c->stream, D, c->g.unit_ptr, c->g.unit_rows, Dc, c->V, c->d);
+  else
+    hipLaunchKernelGGL((k_gather_units<1>), grid, block, 0, c->stream, D, c->g.unit_ptr, c->g.unit_rows, Dc, c->V, c->d);
+  RGCN_HIP(c, hipGetLastError());
   return RGCN_OK;
 }
 

@@ -86,6 +86,19 @@ __device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, si
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += ad[k];
   }
+  if (a.add_units != nullptr) {      // forward direction first, then backward: a fixed order
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const int32_t* up = a.unit_ptr + (size_t)dir * (a.V + 1) + v;
+      const int u = up[0];
+      if (up[1] > u) {
+        float ad[VEC];
+        vload<VEC>(a.add_units + ((size_t)dir * a.V + u) * a.d + (off - (size_t)v * a.d), ad);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += ad[k];
+      }
+    }
+  }
 }
 
 constexpr int kCombineThreads = 256;

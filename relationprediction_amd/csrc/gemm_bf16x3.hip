@@ -66,6 +66,7 @@ struct XArgs {
   int tiles_m, tiles_n, splits;
   int swizzle;
   int vecC;
+  GemmBatch batch;    // groups (blockIdx.y) and their device-side extents
   GemmEpilogue epi;   // EPI != 0 instantiations only
 };
 
@@ -383,17 +384,44 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 
   int wg = blockIdx.x;
   const int total = g.tiles_m * g.tiles_n * g.splits;
-  if (g.swizzle) {
+  if (g.swizzle == 1) {
     const int xcd = wg & 7, idx = wg >> 3;
     const int q = total >> 3, r = total & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int per_split = g.tiles_m * g.tiles_n;
-  const int z = wg / per_split;
+  int z = wg / per_split;
   const int rem = wg - z * per_split;
-  const int m0 = (rem / g.tiles_n) * BM, n0 = (rem % g.tiles_n) * BN;
-  const int ks = z * g.k_per_split;
-  const int ke = min(g.K, ks + g.k_per_split);
+  int m0 = (rem / g.tiles_n) * BM, n0 = (rem % g.tiles_n) * BN;
+  if (g.swizzle == 2) {
+    // groups whose row extent is read on the device (GemmBatch::limit on M): only the leading row panels exist, so they
+    // go round-robin over the XCDs (workgroup i runs on XCD i % 8) -- panel 8 j + x with all its column tiles on XCD x
+    // -- instead of a contiguous range per XCD, which would put all the live tiles on two or three XCDs
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int rp = (idx / g.tiles_n) * 8 + xcd;
+    if (rp >= g.tiles_m) return;
+    z = 0;
+    m0 = rp * BM;
+    n0 = (idx % g.tiles_n) * BN;
+  }
+  // group of this workgroup and its extent (GemmBatch): rows beyond Mlim do not exist, the contraction ends at Klim
+  const int grp = blockIdx.y;
+  int Mlim = g.M, Klim = g.K, kps = g.k_per_split;
+  if (g.batch.limit != nullptr) {
+    const int n = g.batch.limit[grp * g.batch.limit_stride];
+    if (g.batch.limit_on_k) {
+      Klim = min(Klim, max(n, 0));
+      const int per = (Klim + g.splits - 1) / g.splits;
+      kps = max(BK, ((per + BK - 1) / BK) * BK);
+    } else {
+      Mlim = min(Mlim, n);
+      if (m0 >= Mlim) return;
+    }
+  }
+  const float* const gA = g.A + (size_t)grp * g.batch.strideA;
+  const float* const gB = g.B + (size_t)grp * g.batch.strideB;
+  const int ks = z * kps;
+  const int ke = max(ks, min(Klim, ks + kps));
   const int nkt = (ke - ks + BK - 1) / BK;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -414,10 +442,10 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   // Tiles past the end of K load zeros from the zero buffer; the step body is branch-free.
   f32x4 ra[2][2], rb[2][2];
   auto gload = [&](int k0, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
-    if constexpr (A_KC) load_kc<VEC>(g.A, g.zeros, g.lda, g.M, m0, k0, ke, xa);
-    else load_rc<VEC>(g.A, g.zeros, g.lda, g.M, m0, k0, ke, xa);
-    if constexpr (B_KC) load_kc<VEC>(g.B, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
-    else load_rc<VEC>(g.B, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
+    if constexpr (A_KC) load_kc<VEC>(gA, g.zeros, g.lda, Mlim, m0, k0, ke, xa);
+    else load_rc<VEC>(gA, g.zeros, g.lda, Mlim, m0, k0, ke, xa);
+    if constexpr (B_KC) load_kc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
+    else load_rc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
   };
   // Full tiles of a 16-byte-loadable operand are fetched through per-thread walking pointers (one
   // 64-bit add per load and step instead of the whole address + validity computation); a thread whose
@@ -430,20 +458,20 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     for (int p = 0; p < 2; ++p) {
       if constexpr (A_KC) {
         const int f = threadIdx.x + NTH * p, row = m0 + (f >> 2);
-        wa[p] = row < g.M ? g.A + (size_t)row * g.lda + ks + (f & 3) * 4 : g.zeros;
-        ia[p] = row < g.M ? BK : 0;
+        wa[p] = row < Mlim ? gA + (size_t)row * g.lda + ks + (f & 3) * 4 : g.zeros;
+        ia[p] = row < Mlim ? BK : 0;
       } else {
         const int row = m0 + 4 * (threadIdx.x & 31), k = ks + 2 * (threadIdx.x >> 5) + p;
-        wa[p] = row < g.M ? g.A + (size_t)k * g.lda + row : g.zeros;
-        ia[p] = row < g.M ? BK * g.lda : 0;
+        wa[p] = row < Mlim ? gA + (size_t)k * g.lda + row : g.zeros;
+        ia[p] = row < Mlim ? BK * g.lda : 0;
       }
       if constexpr (B_KC) {
         const int f = threadIdx.x + NTH * p, row = n0 + (f >> 2);
-        wb[p] = row < g.N ? g.B + (size_t)row * g.ldb + ks + (f & 3) * 4 : g.zeros;
+        wb[p] = row < g.N ? gB + (size_t)row * g.ldb + ks + (f & 3) * 4 : g.zeros;
         ib[p] = row < g.N ? BK : 0;
       } else {
         const int row = n0 + 4 * (threadIdx.x & 31), k = ks + 2 * (threadIdx.x >> 5) + p;
-        wb[p] = row < g.N ? g.B + (size_t)k * g.ldb + row : g.zeros;
+        wb[p] = row < g.N ? gB + (size_t)k * g.ldb + row : g.zeros;
         ib[p] = row < g.N ? BK * g.ldb : 0;
       }
     }
@@ -554,7 +582,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   if (nkt > 0 && (sign_group(nkt - 1) & 1)) negate_acc();
 
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
-  float* C = g.C + (size_t)z * g.M * g.ldc;
+  float* C = g.C + (size_t)grp * g.batch.strideC + (size_t)z * g.M * g.ldc;
   if constexpr (EPI != 0) {
     // all 128 rows of the product go to LDS at once, so that no accumulator is alive while the epilogue gathers
     float* stage = reinterpret_cast<float*>(lds);
@@ -597,7 +625,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
         const int f = threadIdx.x + NTH * q;
         const int row = f / C4, c4 = f % C4;
         const int grow = m0 + 64 * pass + row, gcol = n0 + 4 * c4;
-        if (grow < g.M && gcol < g.N) {
+        if (grow < Mlim && gcol < g.N) {
           const float4 v = *reinterpret_cast<const float4*>(stage + row * EPI_LD + 4 * c4);
           *reinterpret_cast<float4*>(C + (size_t)grow * g.ldc + gcol) = v;
         }
@@ -615,7 +643,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < g.M) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+          if (row < Mlim) C[(size_t)row * g.ldc + col] = acc[i][j][r];
         }
       }
     }
@@ -639,8 +667,8 @@ hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
     if (e != hipSuccess) return e;
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n * g.splits)), dim3(NTH),
-                     bytes, c->stream, g);
+  const int gx = g.swizzle == 2 ? ((g.tiles_m + 7) / 8) * 8 * g.tiles_n : g.tiles_m * g.tiles_n * g.splits;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)g.batch.groups), dim3(NTH), bytes, c->stream, g);
   return hipGetLastError();
 }
 
@@ -661,9 +689,11 @@ hipError_t launch_form(rgcn_ctx* c, bool a_kc, bool b_kc, const XArgs& g) {
 // Called by gemm_f32() when the context's gemm mode asks for the split evaluation; same contract.
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi) {
+                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi,
+                              const GemmBatch* batch) {
   XArgs g;
   if (epi) g.epi = *epi;
+  if (batch) g.batch = *batch;
   g.A = A; g.B = B; g.C = C; g.zeros = c->zeros;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.k_per_split = k_per_split; g.splits = splits; g.swizzle = swizzle; g.vecC = vecC;

@@ -42,6 +42,7 @@ struct GemmArgs {
   int tiles_m, tiles_n, splits;
   int swizzle;       // XCD-aware workgroup remap
   int vecC;          // 16-byte row-contiguous stores legal (aligned C, ldc % 4 == 0, N % 4 == 0)
+  GemmBatch batch;   // groups (blockIdx.y) and their device-side extents
 };
 
 template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
@@ -141,17 +142,44 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
   // ---- workgroup -> (k-slab, row tile, column tile); XCD-aware so that neighbours share an L2
   int wg = blockIdx.x;
   const int total = g.tiles_m * g.tiles_n * g.splits;
-  if (g.swizzle) {
+  if (g.swizzle == 1) {
     const int xcd = wg & 7, idx = wg >> 3;
     const int q = total >> 3, r = total & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int per_split = g.tiles_m * g.tiles_n;
-  const int z = wg / per_split;
+  int z = wg / per_split;
   const int rem = wg - z * per_split;
-  const int m0 = (rem / g.tiles_n) * BM, n0 = (rem % g.tiles_n) * BN;
-  const int ks = z * g.k_per_split;
-  const int ke = min(g.K, ks + g.k_per_split);
+  int m0 = (rem / g.tiles_n) * BM, n0 = (rem % g.tiles_n) * BN;
+  if (g.swizzle == 2) {
+    // groups whose row extent is read on the device (GemmBatch::limit on M): only the leading row panels exist, so they
+    // go round-robin over the XCDs (workgroup i runs on XCD i % 8) -- panel 8 j + x with all its column tiles on XCD x
+    // -- instead of a contiguous range per XCD, which would put all the live tiles on two or three XCDs
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int rp = (idx / g.tiles_n) * 8 + xcd;
+    if (rp >= g.tiles_m) return;
+    z = 0;
+    m0 = rp * BM;
+    n0 = (idx % g.tiles_n) * BN;
+  }
+  // group of this workgroup and its extent (GemmBatch): rows beyond Mlim do not exist, the contraction ends at Klim
+  const int grp = blockIdx.y;
+  int Mlim = g.M, Klim = g.K, kps = g.k_per_split;
+  if (g.batch.limit != nullptr) {
+    const int n = g.batch.limit[grp * g.batch.limit_stride];
+    if (g.batch.limit_on_k) {
+      Klim = min(Klim, max(n, 0));
+      const int per = (Klim + g.splits - 1) / g.splits;
+      kps = max(BK, ((per + BK - 1) / BK) * BK);
+    } else {
+      Mlim = min(Mlim, n);
+      if (m0 >= Mlim) return;
+    }
+  }
+  const float* const gA = g.A + (size_t)grp * g.batch.strideA;
+  const float* const gB = g.B + (size_t)grp * g.batch.strideB;
+  const int ks = z * kps;
+  const int ke = max(ks, min(Klim, ks + kps));
   const int nkt = (ke - ks + BK - 1) / BK;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,8 +196,8 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
 
   float4 ra[PA], rb[PB];
   if (nkt > 0) {
-    load_tile<A_KC, BM, BK, NT, PA, VEC>(g.A, g.zeros, g.lda, g.M, m0, ks, ke, ra);
-    load_tile<B_KC, BN, BK, NT, PB, VEC>(g.B, g.zeros, g.ldb, g.N, n0, ks, ke, rb);
+    load_tile<A_KC, BM, BK, NT, PA, VEC>(gA, g.zeros, g.lda, Mlim, m0, ks, ke, ra);
+    load_tile<B_KC, BN, BK, NT, PB, VEC>(gB, g.zeros, g.ldb, g.N, n0, ks, ke, rb);
     store_tile<A_KC, BM, BK, NT, PA>(lds, ra);
     store_tile<B_KC, BN, BK, NT, PB>(lds + TA, rb);
   }
@@ -179,8 +207,8 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
     if (more) {   // next tile's global loads fly under this tile's MFMAs
-      load_tile<A_KC, BM, BK, NT, PA, VEC>(g.A, g.zeros, g.lda, g.M, m0, ks + (kt + 1) * BK, ke, ra);
-      load_tile<B_KC, BN, BK, NT, PB, VEC>(g.B, g.zeros, g.ldb, g.N, n0, ks + (kt + 1) * BK, ke, rb);
+      load_tile<A_KC, BM, BK, NT, PA, VEC>(gA, g.zeros, g.lda, Mlim, m0, ks + (kt + 1) * BK, ke, ra);
+      load_tile<B_KC, BN, BK, NT, PB, VEC>(gB, g.zeros, g.ldb, g.N, n0, ks + (kt + 1) * BK, ke, rb);
     }
     const float* a_lds = lds + cur * (TA + TB);
     const float* b_lds = a_lds + TA;
@@ -206,7 +234,7 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
     __syncthreads();
   }
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
-  float* C = g.C + (size_t)z * g.M * g.ldc;   // slab z (ldc == N for slabs)
+  float* C = g.C + (size_t)grp * g.batch.strideC + (size_t)z * g.M * g.ldc;   // slab z of this group (ldc == N for slabs)
   if (g.vecC) {
     // stage 64 output rows at a time through LDS so that every global store is a full 16-byte,
     // row-contiguous access (8x fewer store instructions than the per-register dword stores)
@@ -230,7 +258,7 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
         const int f = threadIdx.x + NT * q;
         const int row = f / C4, c4 = f % C4;
         const int grow = m0 + 64 * pass + row, gcol = n0 + 4 * c4;
-        if (grow < g.M && gcol < g.N) {
+        if (grow < Mlim && gcol < g.N) {
           const float4 v = *reinterpret_cast<const float4*>(lds + row * EPI_LD + 4 * c4);
           *reinterpret_cast<float4*>(C + (size_t)grow * g.ldc + gcol) = v;
         }
@@ -248,7 +276,7 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < g.M) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+          if (row < Mlim) C[(size_t)row * g.ldc + col] = acc[i][j][r];
         }
       }
     }
@@ -257,10 +285,12 @@ __global__ void __launch_bounds__(CF::NT) k_gemm_f32(GemmArgs g) {
 // slabs are added in slab order (fixed summation order); VEC = 4: 16-byte accesses, 8 slab loads in flight
 template <int VEC>
 __global__ void k_splitk_reduce(const float* __restrict__ slab, float* __restrict__ C, int M, int N,
-                                int ldc, int splits) {
+                                int ldc, int splits, size_t group_stride_c) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   const int64_t mn = (int64_t)M * N;
   if (i >= mn) return;
+  slab += (size_t)blockIdx.y * splits * mn;       // group blockIdx.y: its own slabs, its own C
+  C += (size_t)blockIdx.y * group_stride_c;
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
@@ -304,7 +334,8 @@ template <class CF, bool VEC>
 void launch_v(rgcn_ctx* c, bool a_kc, bool b_kc, GemmArgs& g) {
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
   g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(CF::NT);
+  const int gx = g.swizzle == 2 ? ((g.tiles_m + 7) / 8) * 8 * g.tiles_n : g.tiles_m * g.tiles_n * g.splits;
+  dim3 grid((unsigned)gx, (unsigned)g.batch.groups), block(CF::NT);
   static_assert((64 * CF::BN / 4) % CF::NT == 0 && CF::TM * 32 <= 64, "epilogue staging geometry");
   if (a_kc && !b_kc) hipLaunchKernelGGL((k_gemm_f32<true, false, VEC, CF>), grid, block, 0, c->stream, g);
   else if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm_f32<true, true, VEC, CF>), grid, block, 0, c->stream, g);
@@ -324,17 +355,21 @@ int env_int(const char* name, int dflt) {
 
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k, const GemmEpilogue* epi) {
+                     int split_k, const GemmEpilogue* epi, const GemmBatch* batch, double prof_scale) {
   if (M <= 0 || N <= 0) return RGCN_OK;
+  const int groups = batch ? batch->groups : 1;
   if (a_kc == false && b_kc == true) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "gemm TT form not instantiated");
   static const int variant = env_int("RGCN_GEMM_VARIANT", 0);     // tuning knob (tools/gemm_sweep.py)
   static const int swizzle = env_int("RGCN_GEMM_SWIZZLE", 1);
   const int bk = 16;
   GemmArgs g;
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-  const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N);
+  const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N) &&
+                   (!batch || (batch->strideA % 4 == 0 && batch->strideB % 4 == 0));
   g.swizzle = swizzle;
   g.zeros = c->zeros;
+  if (batch) g.batch = *batch;
+  if (batch && batch->limit != nullptr && !batch->limit_on_k && split_k <= 1) g.swizzle = 2;
   if (split_k < 1) split_k = 1;
   int kps = (K + split_k - 1) / split_k;
   kps = ((kps + bk - 1) / bk) * bk;
@@ -344,21 +379,24 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   g.splits = split_k;
   const bool slabs = split_k > 1;
   if (slabs) {
-    if ((size_t)split_k * M * N > c->slab_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: split-K slab too small");
+    if ((size_t)groups * split_k * M * N > c->slab_floats) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: split-K slab too small");
     g.C = c->slab; g.ldc = N;
+    g.batch.strideC = (size_t)split_k * M * N;
   } else {
     g.C = C; g.ldc = ldc;
   }
   static const int staged_store = env_int("RGCN_GEMM_EPILOGUE", 1);
   g.vecC = (staged_store && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
   {
-    ProfScope ps(c, tag, 4.0 * ((double)M * K + (double)K * N + (double)M * N) + (epi ? epi->alg_extra_bytes : 0.0),
-                 2.0 * M * N * K);
+    // (prof_scale: the share of the launch's M x K extent that exists on the device side -- compacted groups)
+    ProfScope ps(c, tag, prof_scale * groups * 4.0 * ((double)M * K + (double)K * N + (double)M * N) +
+                             (epi ? epi->alg_extra_bytes : 0.0),
+                 prof_scale * groups * 2.0 * M * N * K);
     if (epi && epi->mode != 0 && (c->gemm_mode == 0 || slabs || !vec || !g.vecC || ldc != N))
       RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "internal: fused GEMM epilogue outside its domain");
     if (c->gemm_mode != 0) {
       RGCN_HIP(c, gemm_bf16x3_launch(c, c->gemm_mode, a_kc, b_kc, vec, M, N, K, A, lda, B, ldb, g.C, g.ldc,
-                                     g.k_per_split, g.splits, g.swizzle, g.vecC, epi));
+                                     g.k_per_split, g.splits, g.swizzle, g.vecC, epi, &g.batch));
     } else switch (variant) {
       case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
       case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
@@ -368,13 +406,14 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   }
   if (slabs) {
     const int64_t mn = (int64_t)M * N;
-    ProfScope ps(c, "splitk_reduce", 4.0 * mn * (split_k + 1), 0);
-    if (N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0)
-      hipLaunchKernelGGL((k_splitk_reduce<4>), dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, c->stream,
-                         c->slab, C, M, N, ldc, split_k);
+    ProfScope ps(c, "splitk_reduce", 4.0 * groups * mn * (split_k + 1), 0);
+    const size_t gsc = batch ? batch->strideC : 0;
+    if (N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0 && gsc % 4 == 0)
+      hipLaunchKernelGGL((k_splitk_reduce<4>), dim3((unsigned)((mn / 4 + 255) / 256), (unsigned)groups), dim3(256), 0,
+                         c->stream, c->slab, C, M, N, ldc, split_k, gsc);
     else
-      hipLaunchKernelGGL((k_splitk_reduce<1>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, c->stream,
-                         c->slab, C, M, N, ldc, split_k);
+      hipLaunchKernelGGL((k_splitk_reduce<1>), dim3((unsigned)((mn + 255) / 256), (unsigned)groups), dim3(256), 0,
+                         c->stream, c->slab, C, M, N, ldc, split_k, gsc);
     RGCN_HIP(c, hipGetLastError());
   }
   return RGCN_OK;

@@ -32,6 +32,7 @@ struct ScanJob {
   int32_t* out;     // n + 1 entries
   int32_t n;
   int32_t div;      // 0: identity, else value -> ceil(value / div)
+  int32_t* where;   // optional: where[out[i]] = i for every i with in[i] != 0 (the compacted index list of a 0/1 input)
 };
 struct ScanJobs {
   ScanJob j[5];
@@ -75,7 +76,10 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
       int idx = start + k;
-      if (idx < job.n) job.out[idx] = tbase + v[k];
+      if (idx < job.n) {
+        job.out[idx] = tbase + v[k];
+        if (job.where != nullptr && job.in[idx] != 0) job.where[tbase + v[k]] = idx;
+      }
     }
     __syncthreads();
     if (tid == 0) carry_s = carry + total;
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
                                                int32_t* giant_rows, int32_t* giant_first, int32_t* giant_cnt,
                                                int32_t* piece_row, int32_t* piece_k, int32_t* ngiant, int giant_cap,
                                                int piece_cap, int32_t* rel_ptr, int32_t* chunk_ptr,
-                                               uint32_t* row_key) {
+                                               uint32_t* row_key, int32_t* has_dir) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -182,16 +186,23 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   if (v == V) return;
   const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1));
   if (row_key != nullptr) row_key[v] = end - beg > kLongRow ? (uint32_t)(kLongRow + 1) : (uint32_t)(kLongRow - (end - beg));
-  if (degrees_from_rows) {
-    // all relations are local: row v holds every incidence of v, the stable sort put the incidences
-    // with index < E (edges arriving at v) first -> in-degree = position of the first index >= E
+  if (degrees_from_rows || has_dir != nullptr) {
+    // row v holds every LOCAL incidence of v, the stable sort put the incidences with index < E (edges arriving at v:
+    // forward-direction messages) first -> their count = position of the first index >= E.  All relations local: that
+    // is the in-degree
     int lo = beg, hi = end;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (permv[mid] < E) lo = mid + 1; else hi = mid;
     }
-    indeg[v] = lo - beg;
-    outdeg[v] = end - lo;
+    if (degrees_from_rows) {
+      indeg[v] = lo - beg;
+      outdeg[v] = end - lo;
+    }
+    if (has_dir != nullptr) {      // basis kind: which (row, direction) units exist
+      has_dir[v] = lo > beg ? 1 : 0;
+      has_dir[V + v] = end > lo ? 1 : 0;
+    }
   }
   if (end - beg > giant_threshold) {
     // pieces of one row get consecutive ids: the finishing pass adds them in a fixed order
@@ -480,6 +491,12 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
     RGCN_TRY(dalloc(c, &g.s_rel, M));
     RGCN_TRY(dalloc(c, &g.s_norm, M));
   }
+  if (c->kind == RGCN_KIND_BASIS) {
+    RGCN_TRY(dalloc(c, &g.has_dir, 2 * V));
+    RGCN_TRY(dalloc(c, &g.unit_ptr, 2 * (V + 1)));
+    RGCN_TRY(dalloc(c, &g.unit_rows, 2 * V));
+    RGCN_HIP(c, hipMemsetAsync(g.unit_ptr, 0, sizeof(int32_t) * 2 * (V + 1), c->stream));
+  }
   if (c->kind == RGCN_KIND_BLOCK) {
     RGCN_TRY(dalloc(c, &g.row_key, V));
     RGCN_TRY(dalloc(c, &g.row_key_s, V));
@@ -515,7 +532,7 @@ static void graph_free_one(GraphBufs& g, bool owns_shared) {
                   g.keyv, g.keyv_s, g.keyr, g.keyr_s, g.valv, g.permv, g.valr, g.permr, g.pos,
                   g.m_src, g.m_dst, g.m_dslot, g.m_sslot, g.m_norm, g.d_src, g.d_rel, g.d_norm, g.s_dst, g.s_rel,
                   g.s_norm, g.owner, g.errflag, g.keyv_t, g.keyr_t, g.tablev, g.tabler, g.row_key, g.row_key_s, g.row_order,
-                  g.row_tab};
+                  g.row_tab, g.has_dir, g.unit_ptr, g.unit_rows};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g = GraphBufs();
@@ -541,6 +558,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   g.giant_on = c->kind == RGCN_KIND_BLOCK && c->world == 1 && M > 65536;
   g.ready = false;
   g.pf_valid = false;
+  g.units_host = -1;
   c->fwd_done = false;
   const bool zero_in_keys = c->world == 1 && E > 0;      // (sharded: the degree counters are atomically added to)
   if (!zero_in_keys) RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
@@ -564,7 +582,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                        g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows,
                        g.nlong, g.long_cap,
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
-                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr, g.row_key);
+                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr, g.row_key, g.has_dir);
   }
   if (g.row_key != nullptr) {
     // rows by descending length (stable, one 8-bit pass of the library's radix sort over V keys <= 33)
@@ -572,13 +590,24 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                 (uint32_t)(kLongRow + 1)};
     RGCN_TRY(sort_pairs(c, "prep_row_order", 1, &sp));
   }
-  if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
+  {
+    // one launch, one workgroup per scan: the cumulative degrees of the as-executed normalisation, and the
+    // basis kind's (row, direction) units -- index of every unit and the ascending list of their rows
     ScanJobs jobs;
-    jobs.j[0] = {g.indeg, g.cum_in, V, 0};
-    jobs.j[1] = {g.outdeg, g.cum_out, V, 0};
-    jobs.j[2] = jobs.j[3] = jobs.j[4] = jobs.j[0];
-    ProfScope ps(c, "prep_scan", 16.0 * V, 0);
-    hipLaunchKernelGGL(k_exscan, dim3(2), dim3(kScanThreads), 0, c->stream, jobs);
+    int nj = 0;
+    if (c->cfg.norm_mode == RGCN_NORM_TF_AS_EXECUTED) {
+      jobs.j[nj++] = {g.indeg, g.cum_in, V, 0, nullptr};
+      jobs.j[nj++] = {g.outdeg, g.cum_out, V, 0, nullptr};
+    }
+    if (g.has_dir != nullptr) {
+      jobs.j[nj++] = {g.has_dir, g.unit_ptr, V, 0, g.unit_rows};
+      jobs.j[nj++] = {g.has_dir + V, g.unit_ptr + (V + 1), V, 0, g.unit_rows + V};
+    }
+    for (int k = nj; k < 5; ++k) jobs.j[k] = jobs.j[0];
+    if (nj > 0) {
+      ProfScope ps(c, "prep_scan", 8.0 * nj * V, 0);
+      hipLaunchKernelGGL(k_exscan, dim3(nj), dim3(kScanThreads), 0, c->stream, jobs);
+    }
   }
   if (E > 0) {
     ProfScope ps(c, "prep_build_msgs", 12.0 * E + 36.0 * M, 0);

@@ -471,7 +471,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   } else {
     const size_t zc = 2 * (size_t)c->B * d;
     RGCN_TRY(dmalloc(c, &c->msgbuf2, V * zc));
-    RGCN_TRY(dmalloc(c, &c->aggbuf, Vd));
+    RGCN_TRY(dmalloc(c, &c->aggbuf, 2 * V * d));     // [2][V][d]: unit products (forward), gathered upstream rows (backward)
     c->zsave.assign(c->L + 1, nullptr);
     for (int l = 1; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->zsave[l], V * zc));
     const size_t s2 = 16 * zc * d;
@@ -570,6 +570,36 @@ static rgcn_status single_pass(rgcn_ctx* c, const char* tag, int l, bool backwar
   return rows_layer(c) ? block_rows(c, tag, l, backward, X, a) : block_spmm(c, tag, l, backward, X, a);
 }
 
+// Basis kind: the two direction groups of a batched GEMM over the (row, direction) units of the current graph; the
+// group's extent (rows of A / C, or the depth of dW') is the direction's unit count, read on the device.
+static GemmBatch basis_batch(const rgcn_ctx* c, size_t strideA, size_t strideB, size_t strideC, bool limit_on_k) {
+  GemmBatch b;
+  b.groups = 2;
+  b.strideA = strideA; b.strideB = strideB; b.strideC = strideC;
+  b.limit = c->g.unit_ptr + c->V;
+  b.limit_stride = c->V + 1;
+  b.limit_on_k = limit_on_k ? 1 : 0;
+  return b;
+}
+// share of the 2 V possible units that exist (profile accounting only: the kernels read the counts on the device).
+// Exact while the per-kernel profile is on (one readback per graph), the bound min(messages, 2 V) otherwise.
+static double basis_unit_share(rgcn_ctx* c) {
+  const double cap = 2.0 * c->V;
+  if (c->prof_on && !c->capturing) {
+    if (c->g.units_host < 0) {
+      int32_t n[2] = {0, 0};
+      if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
+      (void)hipStreamSynchronize(c->stream);
+      if (hipMemcpy(&n[0], c->g.unit_ptr + c->V, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+          hipMemcpy(&n[1], c->g.unit_ptr + 2 * c->V + 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
+        c->g.units_host = (int64_t)n[0] + n[1];
+    }
+    if (c->g.units_host >= 0) return (double)c->g.units_host / cap;
+  }
+  const double M = 2.0 * c->g.E / c->world;
+  return (M < cap ? M : cap) / cap;
+}
+
 static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
   const float* Hin = c->H[l - 1];
@@ -643,30 +673,32 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     a.drop2 = make_drop(c, l, false);
     RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
   } else {
-    // aggregate first: Z[v,(dir,b),:] = sum n C[rel,b] H[src];  pre = dropout(H.W_self) + Z.W'
-    const int zc = 2 * c->B * d;
+    // aggregate first, per (row, direction) unit: Zc[(v,dir),b,:] = sum n C[rel,b] H[src];
+    // pre[v] = dropout(H.W_self)[v] + sum_dir Zc[(v,dir)] . W'_dir  -- two groups of one batched GEMM over the units
+    const int Bd = c->B * d;
     // the self-loop GEMM needs the layer input only: it runs on side stream 1 beside the aggregation (HBM-bound) and
-    // then beside the basis GEMM, whose last round of tiles leaves CUs idle (RGCN_GEMM_CORUN, as in the backward pass)
-    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
+    // then beside the basis GEMM
     {
-      StreamScope side(c, corun_env ? 1 : -1);
+      StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
                         c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     }
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
-    RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, zc, c->zsave[l], zc, c->layers[l].wrel, d,
-                      c->aggbuf, d, 1));
+    const GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
+    RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
+                      c->aggbuf, d, 1, nullptr, &gb, basis_unit_share(c)));
     RGCN_TRY(stream_join(c, 1));
     CombineArgs a;
-    a.add = c->aggbuf;
+    a.add = nullptr;
+    a.add_units = c->aggbuf; a.unit_ptr = c->g.unit_ptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr;
     a.long_rows = nullptr; a.nlong = nullptr; a.gate = nullptr; a.V = V; a.d = d;
     a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
     a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
     a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(combine(c, "combine_fwd", a, 12.0 * V * d));
+    RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + 2.0 * V * basis_unit_share(c)) + 8.0 * V));
   }
   return RGCN_OK;
 }
@@ -872,26 +904,29 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
                         c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
   } else {
-    const int zc = 2 * c->B * d;
+    const int Bd = c->B * d;
+    // The upstream rows of the units, compacted like Zc (the row operand of dZ, the depth operand of dW')
+    RGCN_TRY(wait_gather(c));            // D_l of every row
+    RGCN_TRY(basis_gather_units(c, c->bwd_D, c->aggbuf));
     // The four dense contractions of the layer depend on D_l / dS_l only.  Two of them -- the weight gradients dW_self =
-    // H^T.dS and dW' = Z^T.D, needed at the end of the pass -- go to side stream 1, the two whose products the gather
-    // kernels below consume (dH's self-loop part, dZ) stay on the main stream: the pairs fill each other's idle CU slots
-    // and tails (RGCN_GEMM_CORUN=0: all four one behind the other).
-    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
+    // H^T.dS and dW'_dir = Zc_dir^T.D[units], needed at the end of the pass -- go to side stream 1, the two whose
+    // products the gather kernels below consume (dH's self-loop part, dZ) stay on the main stream: the pairs fill each
+    // other's idle CU slots and tails.
     {
-      StreamScope side(c, corun_env ? 1 : -1);
+      StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
                         c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-      // dW' = Z^T . D   ([2B.d,V] x [V,d], split over V)
-      RGCN_TRY(wait_gather(c));            // D_l of every row
-      RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, zc, d, V, c->zsave[l], zc, c->bwd_D, d, lb.grel, d,
-                        auto_split_k(zc, d, V)));
+      // dW'_dir = Zc_dir^T . Dc_dir   ([B.d, units] x [units, d], split over the units; two groups)
+      const GemmBatch gk = basis_batch(c, (size_t)V * Bd, (size_t)V * d, (size_t)Bd * d, true);
+      RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, Bd, d, V, c->zsave[l], Bd, c->aggbuf, d, lb.grel, d,
+                        auto_split_k(2 * Bd, d, V), nullptr, &gk, basis_unit_share(c)));
     }
     RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                       c->self_buf + (size_t)lo * d, d, 1));
-    // dZ = D . W'^T   ([V,d] x [d,2B.d])
-    RGCN_TRY(wait_gather(c));            // D_l of every row
-    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, zc, d, c->bwd_D, d, lb.wrel, d, c->msgbuf2, zc, 1));
+    // dZc_dir = Dc_dir . W'_dir^T   ([units, d] x [d, B.d], two groups)
+    const GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
+    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, nullptr, &gm,
+                      basis_unit_share(c)));
     RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
     RGCN_TRY(basis_backward_gather(c, l, c->msgbuf2, a, true));
   }

@@ -216,6 +216,13 @@ struct GraphBufs {
   int32_t *d_src = nullptr, *d_rel = nullptr, *s_dst = nullptr, *s_rel = nullptr;
   float *d_norm = nullptr, *s_norm = nullptr;
   float* m_norm = nullptr;
+  // basis kind: the (row, direction) UNITS of the graph -- row v has a unit of direction dir (0: messages of W_forward,
+  // arriving along an edge; 1: W_backward) iff one of this rank's messages of that direction lands on it.  The dense
+  // contractions of the basis layer run over units, not over all V rows (basis.hip).  has_dir [2][V] 0/1;
+  // unit_ptr [2][V+1] = its exclusive scan (unit index of (v, dir); entry V = number of units); unit_rows [2][V] = the
+  // row of every unit, ascending
+  int32_t *has_dir = nullptr, *unit_ptr = nullptr, *unit_rows = nullptr;
+  int64_t units_host = -1;      // number of units, once somebody has read it back (profile accounting); -1: unknown
   uint32_t *keyv_t = nullptr, *keyr_t = nullptr;   // sort scratch (csr_sort.hip)
   uint16_t *tablev = nullptr, *tabler = nullptr;
   // prefetch bookkeeping (rgcn_prefetch_graph_device): which graph this set was prepared for
@@ -473,17 +480,32 @@ size_t sort_table_elems(size_t n);
 rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* specs);
 
 // ---- gemm_f32.hip
+// Several contractions of one shape in ONE launch (blockIdx.y = group), each with its own operands and -- read on the
+// device, so that nothing about the graph has to come back to the host -- its own extent along M (rows of A and C that
+// exist; workgroups of tiles beyond it leave at once and write nothing) or along K (the depth of the contraction; the
+// split-K slices divide the ACTUAL depth evenly).  The row-compacted basis contraction (basis.hip) is two groups, one
+// per message direction, whose row counts the graph preparation leaves in GraphBufs::unit_ptr.
+struct GemmBatch {
+  int groups = 1;
+  size_t strideA = 0, strideB = 0, strideC = 0;   // floats between consecutive groups' operands
+  const int32_t* limit = nullptr;                 // device, limit[g * limit_stride]: extent of group g (<= M resp. K)
+  int limit_stride = 1;
+  int limit_on_k = 0;                             // 0: rows of A / C; 1: depth K
+};
+
 // C[M,N] (ldc) = A(m,k) . B(k,n).  a_kc: A stored [m][k] (k contiguous, lda) else [k][m];
 // b_kc: B stored [n][k] (k contiguous, ldb) else [k][n].  split_k > 1 writes partial slabs to
-// `slab` ([split_k][M][N]) and reduces them into C deterministically.
+// `slab` ([group][split_k][M][N]) and reduces them into C deterministically.
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k, const GemmEpilogue* epi = nullptr);
+                     int split_k, const GemmEpilogue* epi = nullptr, const GemmBatch* batch = nullptr,
+                     double prof_scale = 1.0);
 
 // gemm_bf16x3.hip: the same contraction on the bf16 matrix cores (exact 3-way operand split)
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi = nullptr);
+                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi = nullptr,
+                              const GemmBatch* batch = nullptr);
 
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);
@@ -513,6 +535,8 @@ struct CombineArgs;
 rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const CombineArgs& ca,
                                   bool with_messages);
 rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* dZ);
+// Dc[dir][i][:] = D[row of unit i of direction dir][:]  (the compacted upstream rows, [2][V][d])
+rgcn_status basis_gather_units(rgcn_ctx* c, const float* D, float* Dc);
 rgcn_status basis_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst);
 rgcn_status basis_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev);
 
@@ -521,7 +545,11 @@ struct CombineArgs {
   float* out;            // primary output [V,d]
   float* out2;           // optional: out * dropout(drop2)
   const float* base;     // optional [V,d] (valid for rows in [row_lo,row_hi)); dropout `drop` applies
-  const float* add;      // optional [V,d] added as is (basis: the Z.W' product)
+  const float* add;      // optional [V,d] added as is
+  // optional (basis kind): the compacted products [2][V][d] of the units of each direction; row v receives the rows
+  // unit_ptr[dir][v] of both directions it has a unit in (GraphBufs::unit_ptr, [2][V+1])
+  const float* add_units = nullptr;
+  const int32_t* unit_ptr = nullptr;
   const float* msg;      // optional message rows [slots,d]; summed per CSR row
   const int32_t* row_ptr;
   const int32_t* long_rows; // rows with more than kLongRow slots (GraphBufs::long_rows / nlong)
