@@ -346,6 +346,8 @@ def measure(workload, args, rk, steps, warmup, full):
     device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" else rk.local_rank
     eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
                          device=device, rank=rank, world=world)
+    if os.environ.get("RGCN_STREAMS", "1") == "0":      # bench.py's own switch (the PMC passes run on one stream)
+        eng.set_overlap(False)
     eng.set_params(params)
     if world > 1:
         # One rank per GPU (launched by torch.distributed.run, which only provides the environment).

@@ -382,25 +382,28 @@ rgcn_status rgcn_copy_to_host(rgcn_ctx* ctx, void* host, const void* dev, int64_
 rgcn_status rgcn_timer_start(rgcn_ctx* ctx);
 rgcn_status rgcn_timer_stop(rgcn_ctx* ctx, float* elapsed_ms); /* synchronises */
 
-/* Side-stream overlap on/off (default on; RGCN_STREAMS=0 in the environment turns it off at create).
- * With overlap off every kernel runs alone on the main stream: per-kernel durations are exclusive. */
+/* Side-stream overlap on/off (default on).  With overlap off every kernel runs alone on the main stream: per-kernel
+ * durations are exclusive.  (The product library reads NO tuning variable from the environment: its configuration is
+ * what these setters say; experiment knobs exist in librgcn_devtools.so only, include/rgcn_devtools.h.) */
 rgcn_status rgcn_set_overlap(rgcn_ctx* ctx, int32_t on);
 
 /* Form of the block-diagonal layer (ConcatGcn.compute_messages + combine_messages, gcn_basis_concat.py:35-83, and
- * their gradient) on one GPU; RGCN_FUSE in the environment sets it at create.  All four give bitwise the same
- * activations and gradients (tests/test_gpu_parity.py::test_fused_layer_kernel_equals_the_two_kernel_form).
- *   3 : (default since round 4) destination-major banded single pass (csrc/block_rows.hip): ONE kernel per layer and
- *       direction walks the incidence CSR -- a 16-lane group per (row, column band), one band per XCD, the relation's
- *       sd x sd blocks read through L2 from a band-tiled copy of the weights, rows taken by descending length, long
- *       rows by whole workgroups through LDS tiles -- and applies self-loop term, dropout and relu / relu'; no message
- *       buffer.  39 / 46 us per layer forward / backward against 57 / 74 for form 0 at FB15k-237 minibatch size, half
- *       the time at the 272,115-edge training graph (profiles/r04_rowmajor_spmm_ab.md).
- *   0 : relation-major message kernel -> [2E,d] message buffer -> row-major reduce (k_combine)
- *   1 : as 0, with the reduce as the epilogue of the self-loop GEMM (the product never travels; measured slower)
- *   2 : round 3's single pass (csrc/block_spmm.hip): per-block workgroups, LDS-resident weight table (needs 2R x sd^2
- *       floats of LDS), 20-byte gathers; 2.4x slower than form 0 at minibatch scale, 3.7x at 272 k edges.
- * The basis kind runs its own kernels whatever the setting; on relation-sharded contexts (world > 1) form 3 walks the
- * rank's own messages and writes the partial pre-activations for the exchange (since round 4), forms 1 / 2 fall back to 0. */
+ * their gradient).  Both give bitwise the same activations and gradients -- with one exception, the embedding bias
+ * gradient db_emb, which form 1 sums from the per-workgroup column partials of its row-gradient kernel (within 2e-6 of
+ * scale of form 0's separate column-sum pass, bit-identical from engine to engine) --
+ * tests/test_gpu_parity.py::test_single_pass_layer_equals_the_two_kernel_form.
+ *   1 : (default) destination-major banded single pass (csrc/block_rows.hip): ONE kernel per layer and direction walks
+ *       the incidence CSR -- a 16-lane group per (row, column band), one band per XCD, the relation's sd x sd blocks
+ *       read through L2 from a band-tiled copy of the weights, rows taken by descending length, long rows by whole
+ *       workgroups through LDS tiles -- and applies self-loop term, dropout and relu / relu'; no message buffer.
+ *       39 / 46 us per layer forward / backward against 57 / 74 for form 0 at FB15k-237 minibatch size, half the time
+ *       at the 272,115-edge training graph (profiles/r04_rowmajor_spmm_ab.md).  On relation-sharded contexts
+ *       (world > 1) it walks the rank's own messages and writes the partial pre-activations for the exchange.
+ *   0 : relation-major message kernel -> [2E,d] message buffer -> row-major reduce (k_combine): the reference form the
+ *       other is held equal to, and what runs when the block count exceeds form 1's lane groups.
+ * (Rounds 2-3 built two more forms -- the reduce as the self-loop GEMM's epilogue, per-block workgroups with an LDS
+ * weight table --, measured them slower and removed them in round 5: profiles/r02_fused_layer_ab.log,
+ * profiles/r03_block_spmm_ab.md.)  The basis kind runs its own kernels whatever the setting. */
 rgcn_status rgcn_set_fusion(rgcn_ctx* ctx, int32_t mode);
 
 /* Arithmetic of the dense contractions (self-loop and basis GEMMs); all of them take and return fp32.

@@ -651,8 +651,8 @@ class Engine:
         self._check(self.lib.rgcn_set_overlap(self.ctx, 1 if on else 0))
 
     def set_fusion(self, mode):
-        """form of the block layer: 0 two kernels + message buffer, 1 GEMM-epilogue fusion, 2 single-pass block SpMM
-        (per-block workgroups, LDS weight table), 3 destination-major banded single pass (block_rows.hip)"""
+        """form of the block layer: 0 two kernels + message buffer, 1 (default) destination-major banded single pass
+        (block_rows.hip)"""
         self._check(self.lib.rgcn_set_fusion(self.ctx, int(mode)))
 
     def set_gemm_mode(self, mode):

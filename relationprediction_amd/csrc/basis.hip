@@ -432,6 +432,26 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
+// Number of (row, direction) units of the current graph, for the profile accounting only (the kernels read the counts
+// on the device).  Exact while the per-kernel profile is on (one readback per graph), the bound min(messages, 2 V)
+// otherwise.
+double basis_units(rgcn_ctx* c) {
+  const double cap = 2.0 * c->V;
+  if (c->prof_on && !c->capturing) {
+    if (c->g.units_host < 0) {
+      int32_t n[2] = {0, 0};
+      if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
+      (void)hipStreamSynchronize(c->stream);
+      if (hipMemcpy(&n[0], c->g.unit_ptr + c->V, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+          hipMemcpy(&n[1], c->g.unit_ptr + 2 * c->V + 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
+        c->g.units_host = (int64_t)n[0] + n[1];
+    }
+    if (c->g.units_host >= 0) return (double)c->g.units_host;
+  }
+  const double M = 2.0 * c->g.E / c->world;
+  return M < cap ? M : cap;
+}
+
 rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, float* Z) {
   AggArgs a;
   a.Hin = Hin; a.Z = Z; a.row_ptr = c->g.row_ptr; a.d_src = c->g.d_src; a.d_rel = c->g.d_rel;
@@ -449,7 +469,7 @@ rgcn_status basis_aggregate_forward(rgcn_ctx* c, int layer, const float* Hin, fl
     a.b0 = b0;
     a.nbt = c->B - b0 < BT ? c->B - b0 : BT;
     const double rows = M < c->V ? M : (double)c->V;     // compulsory: each gathered row of H once
-    const double units = M < 2.0 * c->V ? M : 2.0 * c->V;   // (at most one unit per message)
+    const double units = basis_units(c);
     ProfScope ps(c, "basis_aggregate", 4.0 * c->d * (M + a.nbt * units) + 20.0 * M, 4.0 * M * a.nbt * c->d,
                  4.0 * c->d * (rows + a.nbt * units) + 20.0 * M);
 #define RGCN_LAUNCH_AGG(VEC, TPR) \
@@ -482,7 +502,7 @@ rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const
   const int nlb = with_messages ? long_blocks(c) : 0;
   dim3 grid(nlb + (c->V + rpb - 1) / rpb), block(kRowThreads);
   const double M = 2.0 * c->g.E / c->world;
-  const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
+  const double units = basis_units(c);
   // compulsory: dZ of every unit once, base / gate / out / out2 once each
   ProfScope ps(c, "basis_bwd_gather", 4.0 * c->d * (M * c->B + 4.0 * c->V) + 20.0 * M, 2.0 * M * c->B * c->d,
                4.0 * c->d * (c->B * units + 4.0 * c->V) + 20.0 * M);
@@ -510,7 +530,7 @@ rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* d
     a.R = c->R; a.B = c->B; a.d = c->d; a.chunk = c->g.chunk;
     const double M = 2.0 * c->g.E / c->world;
     const double rows = M < c->V ? M : (double)c->V;
-    const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
+    const double units = basis_units(c);
     ProfScope ps(c, "basis_dcoef", 4.0 * c->d * M * (1.0 + c->B), 2.0 * M * c->B * c->d,
                  4.0 * c->d * (rows + c->B * units) + 16.0 * M);
     if (c->d % 4 == 0 && aligned16(Hin) && aligned16(dZ))
@@ -530,8 +550,7 @@ rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* d
 }
 
 rgcn_status basis_gather_units(rgcn_ctx* c, const float* D, float* Dc) {
-  const double M = 2.0 * c->g.E / c->world;
-  const double units = M < 2.0 * c->V ? M : 2.0 * c->V;
+  const double units = basis_units(c);
   ProfScope ps(c, "basis_gather_units", 8.0 * c->d * units + 8.0 * units, 0);
   dim3 grid((unsigned)((c->V + 1) / 2), 2), block(256);
   if (c->d % 4 == 0 && aligned16(D) && aligned16(Dc))

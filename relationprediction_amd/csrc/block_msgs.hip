@@ -211,9 +211,7 @@ rgcn_status block_geometry(rgcn_ctx* c) {
     RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "block size d/nb must be one of 1,2,3,4,5,8");
   int best_block = 0, best_g = 0;
   double best_util = 0.0;
-  // RGCN_MSG_BLOCK: upper bound on the workgroup size considered (tuning knob; default 512)
-  static const int blk_max = getenv("RGCN_MSG_BLOCK") ? atoi(getenv("RGCN_MSG_BLOCK")) : 512;
-  for (int blk = 64; blk <= 512 && blk <= (blk_max >= 64 ? blk_max : 512); blk += 64) {
+  for (int blk = 64; blk <= 512; blk += 64) {
     int g = blk / c->nb;
     if (g < 1) continue;
     if (g > 8) g = 8;

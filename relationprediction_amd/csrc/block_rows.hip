@@ -27,7 +27,7 @@
 //   * giant rows (full-graph scale, more than kGiantRow slots): kGiantRow-slot pieces, one workgroup each, into the piece
 //     slab; k_combine's finishing pass (elementwise.hip) adds a row's pieces in piece order.
 // Every sum is formed in EXACTLY k_combine's order and every message with k_block_msg_fwd / _bwd's arithmetic, so this
-// kernel and the two-kernel form agree BITWISE (tests/test_gpu_parity.py::test_fused_layer_kernel_equals_the_two_kernel_form, mode 3).
+// kernel and the two-kernel form agree BITWISE (tests/test_gpu_parity.py::test_single_pass_layer_equals_the_two_kernel_form).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -629,17 +629,14 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
   a.giant_len = giant ? kGiantRow : 0x7fffffff;
   a.base = ca.base; a.gate = ca.gate; a.out = ca.out; a.out2 = ca.out2; a.drop = ca.drop; a.drop2 = ca.drop2;
   a.V = c->V; a.d = c->d; a.nb = c->nb; a.relu = ca.relu; a.row_lo = ca.row_lo; a.row_hi = ca.row_hi;
-  static const int rpw_env = getenv("RGCN_ROWS_PER_WG") ? atoi(getenv("RGCN_ROWS_PER_WG")) : 0;
-  static const int lwg_env = getenv("RGCN_ROWS_LONG_WG") ? atoi(getenv("RGCN_ROWS_LONG_WG")) : 0;
   // rows of a short-row workgroup: a multiple of 4 NG (whole turns for its four wavefronts), at most 256
   {
     const int quantum = 4 * (64 / rows_group_width(c));
-    int rpw = rpw_env > 0 ? rpw_env : 64;
-    rpw = std::max(quantum, std::min(256, rpw / quantum * quantum));
+    const int rpw = std::max(quantum, std::min(256, 64 / quantum * quantum));
     a.rows_per_wg = rpw;
   }
   // one workgroup per long row and turn: about one per 256 slots of the graph, 32 .. 1024 workgroups per band
-  int64_t want = lwg_env > 0 ? lwg_env : (2 * c->g.E) / 256;
+  const int64_t want = (2 * c->g.E) / 256;
   a.n_long_wg = c->g.E > 0 ? (int)std::max<int64_t>(32, std::min<int64_t>(1024, want)) : 0;
   const int n_row_wg = (c->V + a.rows_per_wg - 1) / a.rows_per_wg;
   const int grid = 8 * (a.n_long_wg + n_row_wg);
@@ -648,8 +645,7 @@ rgcn_status block_rows(rgcn_ctx* c, const char* tag, int layer, bool backward, c
   a.colpart = nullptr;
   c->colsum_parts = 0;
   const int giant_parts = giant ? c->g.giant_cap : 0;
-  static const int colsum_env = getenv("RGCN_ROWS_COLSUM") ? atoi(getenv("RGCN_ROWS_COLSUM")) : 1;
-  if (backward && ca.colsum && colsum_env != 0 && c->colsum_part != nullptr &&
+  if (backward && ca.colsum && c->colsum_part != nullptr &&
       (size_t)(grid / 8 + giant_parts) * c->d <= c->colsum_part_floats) {
     a.colpart = c->colsum_part;
     c->colsum_parts = grid / 8 + giant_parts;

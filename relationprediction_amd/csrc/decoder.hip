@@ -906,9 +906,8 @@ rgcn_status decoder_prepare(rgcn_ctx* c, const int32_t* X, int64_t N64, int64_t 
   q.N_total = N_total > 0 ? N_total : N64;
   q.X = X;
   // a batch the negative sampler tiled (DecoderBufs::tiled_X): sort its first `period` triples by relation and expand
-  static const bool tiled_order = !(getenv("RGCN_DEC_TILED") && atoi(getenv("RGCN_DEC_TILED")) == 0);
   int period = 0, copies = 1;
-  if (tiled_order && X == q.tiled_X && N64 == q.tiled_N && (N_total <= 0 || N_total == N64) && q.tiled_period > 1 &&
+  if (X == q.tiled_X && N64 == q.tiled_N && (N_total <= 0 || N_total == N64) && q.tiled_period > 1 &&
       N64 % q.tiled_period == 0) {
     period = (int)q.tiled_period;
     copies = (int)(N64 / q.tiled_period);
@@ -966,9 +965,8 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
   const double Nd = (double)Nt * d;
   const float k = (float)(2.0 * reg_param / Nd);
   // energies + loss terms (+ the relation gradient's chunk partials when the rows fit a wave's registers)
-  static const int fused_env = getenv("RGCN_DEC_FUSED") ? atoi(getenv("RGCN_DEC_FUSED")) : 1;
   const int nvec_e = vec4 ? d / 4 : d;
-  const bool fused = fused_env != 0 && nvec_e <= 256;
+  const bool fused = nvec_e <= 256;
   if (fused) {
     const int T = nvec_e <= 64 ? 1 : (nvec_e <= 128 ? 2 : 4);
     const size_t lds = ((size_t)4 * d + 8) * sizeof(float);
@@ -998,7 +996,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     // dL/dW_relation depends on dx only and is not needed before the optimizer: side stream 2, so that it runs
     // beside the entity gradient (forked right behind the energy kernel) and the encoder's backward pass (the caller
     // joins it: stream_join(c, 2))
-    StreamScope side(c, 2, 2);
+    StreamScope side(c, 2);
     // the loss itself (one workgroup summing the kernel's partials) is nobody's input on the device: it goes there too
     hipLaunchKernelGGL(k_dec_loss, dim3(1), dim3(256), 0, c->stream, q.loss_part, fused ? q.max_chunks : q.energy_blocks,
                        Nt, d, reg_param, q.loss);
@@ -1024,10 +1022,9 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
     a.k = k;
     a.dcodes_drop = (dcodes_drop != nullptr && drop != nullptr && drop->mode != DROP_NONE) ? dcodes_drop : nullptr;
     if (drop != nullptr) a.drop = *drop; else a.drop = DropSpec{DROP_NONE, 0, 0, 1.0f, 0, nullptr, nullptr};
-    // line form (default when the rows are float4-addressable): RGCN_DEC_LINES=0 selects the full-row kernel, whose
-    // sums it reproduces bit for bit (tests/test_gpu_train_step.py::test_entity_gradient_forms_are_bitwise_equal)
-    const char* lines_env = getenv("RGCN_DEC_LINES");
-    const bool lines = vec4 && !(lines_env && atoi(lines_env) == 0) && (int64_t)V * kLine * 4 < (1ll << 32);
+    // line form (whenever the rows are float4-addressable); the devtools build's RGCN_DEC_LINES=0 selects the full-row
+    // kernel, whose sums it reproduces bit for bit (tests/test_gpu_train_step.py::test_entity_gradient_forms_are_bitwise_equal)
+    const bool lines = vec4 && knob("RGCN_DEC_LINES", 1) != 0 && (int64_t)V * kLine * 4 < (1ll << 32);
     if (lines) {
       {
         ProfScope ps(c, "dec_band_tables", (4.0 * d + 4.0 * kLine * q.nbands) * ((double)V + R), 0);
@@ -1043,8 +1040,7 @@ rgcn_status decoder_compute(rgcn_ctx* c, const float* codes, const float* Y, flo
       const size_t lds = (size_t)R * kLine * sizeof(float);
       const bool rlds = lds <= 64 * 1024;
       // persistent workgroups: three per CU (measured: 768 workgroups 123 us, 1,024: 127, 512: 132), a multiple of 8
-      static const int wgs_env = getenv("RGCN_DEC_WGS") ? atoi(getenv("RGCN_DEC_WGS")) : 0;
-      const int wgs = wgs_env > 0 ? wgs_env : 12 / kLineWaves * q.cus;
+      const int wgs = 12 / kLineWaves * q.cus;
       dim3 grid((unsigned)((wgs + 7) / 8 * 8)), block(64 * kLineWaves);
       // design: one line of the partner row and of the relation row per incidence and band (what the kernel asks of the
       // L2s) + the index lists once per band + the rows written; compulsory as for the full-row kernel

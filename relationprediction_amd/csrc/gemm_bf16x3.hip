@@ -67,7 +67,6 @@ struct XArgs {
   int swizzle;
   int vecC;
   GemmBatch batch;    // groups (blockIdx.y) and their device-side extents
-  GemmEpilogue epi;   // EPI != 0 instantiations only
 };
 
 constexpr int BM = 128, BN = 128, BK = 16, NTH = 256;
@@ -231,152 +230,7 @@ __device__ __forceinline__ bf16x8 load_frag(const uint32_t* __restrict__ plane, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// Fused combine epilogue (GemmEpilogue): the 64 staged rows of the product, 32 lanes x float4 per row, 8 rows per
-// thread.  The thread first fetches its rows' slot ranges, then walks all of them together -- 8 rows x 4 slots = up to
-// 32 independent 16-byte loads in flight per lane and turn -- adding the message rows in slot order onto the (dropout-
-// scaled) product: the very order k_combine uses, so both paths round alike.  Rows with more than kLongRow slots are
-// summed afterwards by the whole workgroup, 8 slot lanes x 32 column lanes with a fixed-order LDS combine, again in
-// k_combine's order.
-template <int EPI>
-__device__ __forceinline__ void fused_finish(const XArgs& g, float* __restrict__ C, int v, int gcol, f32x4 y) {
-#pragma clang fp contract(off)
-  const GemmEpilogue& e = g.epi;
-  const size_t off = (size_t)v * g.ldc + gcol;
-  if constexpr (EPI == 1) {
-    if (e.relu) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.0f);
-    }
-    *reinterpret_cast<f32x4*>(C + off) = y;
-  } else {
-    if (e.gate != nullptr) {
-      const f32x4 gt = *reinterpret_cast<const f32x4*>(e.gate + off);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = gt[k] > 0.0f ? y[k] : 0.0f;
-    }
-    *reinterpret_cast<f32x4*>(C + off) = y;
-    if (e.out2 != nullptr) {
-      f32x4 o2;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o2[k] = y[k] * drop_factor(e.drop2, off + k);
-      *reinterpret_cast<f32x4*>(e.out2 + off) = o2;
-    }
-  }
-}
-
-template <int EPI>
-__device__ __forceinline__ void fused_rows(const XArgs& g, float* __restrict__ stage, float* __restrict__ scratch,
-                                           float* __restrict__ C, int m0, int n0, int pass) {
-#pragma clang fp contract(off)
-  constexpr int C4 = BN / 4, RSTEP = NTH / C4, Q = 64 / RSTEP;        // 32 column lanes, 8 row lanes, 8 rows per thread
-  constexpr int KU = 2;
-  const GemmEpilogue& e = g.epi;
-  const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
-  const int gcol = n0 + 4 * c4;
-  const bool colok = gcol < g.N;
-  // scratch: the long-row flags of this pass [64], then the long rows' partial sums [8][128]
-  int* longflag = reinterpret_cast<int*>(scratch);
-  if (threadIdx.x < 64) {
-    const int v = m0 + 64 * pass + threadIdx.x;
-    longflag[threadIdx.x] = (v < g.M && e.row_ptr[v + 1] - e.row_ptr[v] > kLongRow) ? 1 : 0;
-  }
-  const float* src[Q];
-  int cnt[Q];
-  int kmax = 0;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int v = m0 + 64 * pass + r0 + RSTEP * q;
-    cnt[q] = 0;
-    src[q] = g.zeros;
-    if (colok && v < g.M) {
-      const int beg = e.row_ptr[v], n = e.row_ptr[v + 1] - beg;
-      if (n <= kLongRow) {
-        src[q] = e.msg + (size_t)beg * g.ldc + gcol;
-        cnt[q] = n;
-      }
-    }
-    kmax = max(kmax, cnt[q]);
-  }
-  f32x4 x[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int row = r0 + RSTEP * q, v = m0 + 64 * pass + row;
-    x[q] = *reinterpret_cast<const f32x4*>(stage + row * EPI_LD + 4 * c4);
-    if constexpr (EPI == 1) {
-      if (colok && v < g.M) {
-        const size_t off = (size_t)v * g.ldc + gcol;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[q][k] = x[q][k] * drop_factor(e.drop, off + k);
-      }
-    }
-  }
-  for (int k = 0; k < kmax; k += KU) {
-    f32x4 m[Q][KU];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const float* p = k + u < cnt[q] ? src[q] + (size_t)(k + u) * g.ldc : g.zeros;
-        m[q][u] = *reinterpret_cast<const f32x4*>(p);
-      }
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-      for (int u = 0; u < KU; ++u)
-        if (k + u < cnt[q]) x[q] = x[q] + m[q][u];
-  }
-  __syncthreads();      // long flags visible; every thread has read its staged values
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int row = r0 + RSTEP * q, v = m0 + 64 * pass + row;
-    if (!(colok && v < g.M)) continue;
-    if (longflag[row]) {
-      // park the (scaled) product value: the workgroup adds the row's slot sum below
-      *reinterpret_cast<f32x4*>(stage + row * EPI_LD + 4 * c4) = x[q];
-      continue;
-    }
-    fused_finish<EPI>(g, C, v, gcol, x[q]);
-  }
-  // long rows of this pass: 8 slot lanes (r0) x 32 column lanes (c4), slot lane sl sums slots beg+sl, beg+sl+8, ...
-  float* red = scratch + 64;
-  for (int row = 0; row < 64; ++row) {
-    if (!longflag[row]) continue;            // uniform over the workgroup
-    const int v = m0 + 64 * pass + row;
-    const int beg = e.row_ptr[v], end = e.row_ptr[v + 1];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (colok) {
-      const float* mp = e.msg + gcol;
-      int s = beg + r0;
-      for (; s + 8 * 15 < end; s += 8 * 16) {
-        f32x4 mm[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) mm[u] = *reinterpret_cast<const f32x4*>(mp + (size_t)(s + 8 * u) * g.ldc);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = acc + mm[u];
-      }
-      for (; s + 24 < end; s += 32) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(mp + (size_t)(s + 0) * g.ldc);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(mp + (size_t)(s + 8) * g.ldc);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(mp + (size_t)(s + 16) * g.ldc);
-        const f32x4 a3 = *reinterpret_cast<const f32x4*>(mp + (size_t)(s + 24) * g.ldc);
-        acc = (((acc + a0) + a1) + a2) + a3;
-      }
-      for (; s < end; s += 8) acc = acc + *reinterpret_cast<const f32x4*>(mp + (size_t)s * g.ldc);
-    }
-    *reinterpret_cast<f32x4*>(red + r0 * 128 + 4 * c4) = acc;
-    __syncthreads();
-    if (r0 == 0 && colok) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(red + 4 * c4);
-#pragma unroll
-      for (int sl = 1; sl < 8; ++sl) t = t + *reinterpret_cast<const f32x4*>(red + sl * 128 + 4 * c4);
-      const f32x4 base = *reinterpret_cast<const f32x4*>(stage + row * EPI_LD + 4 * c4);
-      fused_finish<EPI>(g, C, v, gcol, base + t);
-    }
-    __syncthreads();
-  }
-}
-
-template <bool A_KC, bool B_KC, bool VEC, int TERMS, int EPI = 0>
+template <bool A_KC, bool B_KC, bool VEC, int TERMS>
 __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   constexpr int PA = A_KC ? KC_PLANE : RC_PLANE, PB = B_KC ? KC_PLANE : RC_PLANE;
   constexpr int TA = 3 * PA, TB = 3 * PB;
@@ -583,26 +437,6 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 
   // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
   float* C = g.C + (size_t)grp * g.batch.strideC + (size_t)z * g.M * g.ldc;
-  if constexpr (EPI != 0) {
-    // all 128 rows of the product go to LDS at once, so that no accumulator is alive while the epilogue gathers
-    float* stage = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-          stage[row * EPI_LD + wn + 32 * j + li] = acc[i][j][r];
-        }
-    __syncthreads();
-    float* scratch = stage + 128 * EPI_LD;
-    for (int pass = 0; pass < 2; ++pass) {
-      fused_rows<EPI>(g, stage + pass * 64 * EPI_LD, scratch, C, m0, n0, pass);
-      __syncthreads();
-    }
-    return;
-  }
   if (g.vecC) {
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -649,17 +483,16 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     }
 }
 
-constexpr size_t lds_bytes(bool a_kc, bool b_kc, int epi_mode = 0) {
+constexpr size_t lds_bytes(bool a_kc, bool b_kc) {
   const size_t tiles = 2 * 3 * ((a_kc ? KC_PLANE : RC_PLANE) + (b_kc ? KC_PLANE : RC_PLANE)) * 4;
-  // plain: 64 staged rows; fused: all 128 rows + long-row flags + long-row partial sums
-  const size_t epi = epi_mode ? (128 * EPI_LD + 64 + 8 * 128) * 4 : 64 * EPI_LD * 4;
+  const size_t epi = 64 * EPI_LD * 4;       // 64 staged rows of the product
   return tiles > epi ? tiles : epi;
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TERMS, int EPI = 0>
+template <bool A_KC, bool B_KC, bool VEC, int TERMS>
 hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
-  constexpr size_t bytes = lds_bytes(A_KC, B_KC, EPI);
-  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS, EPI>;
+  constexpr size_t bytes = lds_bytes(A_KC, B_KC);
+  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS>;
   static bool configured = false;     // per instantiation; contexts are single-threaded per process
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -674,11 +507,6 @@ hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
 
 template <bool VEC, int TERMS>
 hipError_t launch_form(rgcn_ctx* c, bool a_kc, bool b_kc, const XArgs& g) {
-  if constexpr (VEC) {      // fused epilogues: full 16-byte rows only (the caller checks), forward on NN, backward on NT
-    if (g.epi.mode == 1 && a_kc && !b_kc) return launch_one<true, false, true, TERMS, 1>(c, g);
-    if (g.epi.mode == 2 && a_kc && b_kc) return launch_one<true, true, true, TERMS, 2>(c, g);
-  }
-  if (g.epi.mode != 0) return hipErrorInvalidValue;
   if (a_kc && !b_kc) return launch_one<true, false, VEC, TERMS>(c, g);
   if (a_kc && b_kc) return launch_one<true, true, VEC, TERMS>(c, g);
   return launch_one<false, false, VEC, TERMS>(c, g);
@@ -689,10 +517,8 @@ hipError_t launch_form(rgcn_ctx* c, bool a_kc, bool b_kc, const XArgs& g) {
 // Called by gemm_f32() when the context's gemm mode asks for the split evaluation; same contract.
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi,
-                              const GemmBatch* batch) {
+                              int k_per_split, int splits, int swizzle, int vecC, const GemmBatch* batch) {
   XArgs g;
-  if (epi) g.epi = *epi;
   if (batch) g.batch = *batch;
   g.A = A; g.B = B; g.C = C; g.zeros = c->zeros;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -346,27 +346,20 @@ void launch(rgcn_ctx* c, bool a_kc, bool b_kc, GemmArgs& g, bool vec) {
   if (vec) launch_v<CF, true>(c, a_kc, b_kc, g); else launch_v<CF, false>(c, a_kc, b_kc, g);
 }
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
-
 }  // namespace
 
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k, const GemmEpilogue* epi, const GemmBatch* batch, double prof_scale) {
+                     int split_k, const GemmBatch* batch, double prof_scale) {
   if (M <= 0 || N <= 0) return RGCN_OK;
   const int groups = batch ? batch->groups : 1;
   if (a_kc == false && b_kc == true) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "gemm TT form not instantiated");
-  static const int variant = env_int("RGCN_GEMM_VARIANT", 0);     // tuning knob (tools/gemm_sweep.py)
-  static const int swizzle = env_int("RGCN_GEMM_SWIZZLE", 1);
   const int bk = 16;
   GemmArgs g;
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
   const bool vec = vec_ok(A, lda, a_kc ? K : M) && vec_ok(B, ldb, b_kc ? K : N) &&
                    (!batch || (batch->strideA % 4 == 0 && batch->strideB % 4 == 0));
-  g.swizzle = swizzle;
+  g.swizzle = 1;
   g.zeros = c->zeros;
   if (batch) g.batch = *batch;
   if (batch && batch->limit != nullptr && !batch->limit_on_k && split_k <= 1) g.swizzle = 2;
@@ -385,22 +378,16 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
   } else {
     g.C = C; g.ldc = ldc;
   }
-  static const int staged_store = env_int("RGCN_GEMM_EPILOGUE", 1);
-  g.vecC = (staged_store && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
+  g.vecC = ((reinterpret_cast<uintptr_t>(g.C) & 15u) == 0 && g.ldc % 4 == 0 && N % 4 == 0) ? 1 : 0;
   {
     // (prof_scale: the share of the launch's M x K extent that exists on the device side -- compacted groups)
-    ProfScope ps(c, tag, prof_scale * groups * 4.0 * ((double)M * K + (double)K * N + (double)M * N) +
-                             (epi ? epi->alg_extra_bytes : 0.0),
+    ProfScope ps(c, tag, prof_scale * groups * 4.0 * ((double)M * K + (double)K * N + (double)M * N),
                  prof_scale * groups * 2.0 * M * N * K);
-    if (epi && epi->mode != 0 && (c->gemm_mode == 0 || slabs || !vec || !g.vecC || ldc != N))
-      RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "internal: fused GEMM epilogue outside its domain");
     if (c->gemm_mode != 0) {
       RGCN_HIP(c, gemm_bf16x3_launch(c, c->gemm_mode, a_kc, b_kc, vec, M, N, K, A, lda, B, ldb, g.C, g.ldc,
-                                     g.k_per_split, g.splits, g.swizzle, g.vecC, epi, &g.batch));
-    } else switch (variant) {
-      case 8: launch<Cfg<128, 128, 16, 2, 4>>(c, a_kc, b_kc, g, vec); break;
-      case 11: launch<Cfg<128, 128, 16, 2, 2>>(c, a_kc, b_kc, g, vec); break;
-      default: launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec); break;
+                                     g.k_per_split, g.splits, g.swizzle, g.vecC, &g.batch));
+    } else {
+      launch<Cfg<128, 128, 16, 4, 2>>(c, a_kc, b_kc, g, vec);
     }
     RGCN_HIP(c, hipGetLastError());
   }

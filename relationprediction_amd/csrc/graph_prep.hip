@@ -552,7 +552,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   // messages per relation chunk: 48 at minibatch scale, growing with THIS graph's size so that a full graph
   // does not cut a popular relation into thousands of chunks (a context serves 15,000-edge training steps and
   // the 272,115-edge evaluation pass alike); the capacity-scaled c->chunk is the upper bound the slabs are sized for
-  g.chunk = c->chunk_fixed ? c->chunk : std::min(c->chunk, 48 * (int)std::max<int64_t>(1, ((int64_t)M + 65535) / 65536));
+  g.chunk = std::min(c->chunk, 48 * (int)std::max<int64_t>(1, ((int64_t)M + 65535) / 65536));
   // giant-row cut: full-graph scale, block kind, one GPU (the basis gathers and the sharded finish walk the long-row
   // list themselves)
   g.giant_on = c->kind == RGCN_KIND_BLOCK && c->world == 1 && M > 65536;

@@ -438,8 +438,6 @@ rgcn_status neighborhood_reserve(rgcn_ctx* c, const int32_t* tri, int64_t n64) {
     int launches = kSweepLaunches;
     while (launches < kMaxSweepLaunches && sweeps_of_budget(launches) < sweeps) ++launches;
     q.launches = launches;
-    if (const char* e = getenv("RGCN_NBR_LAUNCHES"))     // a smaller budget, for measuring how many launches a graph needs
-      q.launches = std::min(q.launches, std::max(atoi(e), 1));
   }
   const size_t nb = (size_t)((n + kCompactBlock - 1) / kCompactBlock) + 1;
   RGCN_TRY(dalloc(c, &q.triples, 3 * (size_t)n));

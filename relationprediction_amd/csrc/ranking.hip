@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_rank_rows(const float* __restrict__ S, 
                                                    int n, int predict_object, const int64_t* __restrict__ filt_ptr,
                                                    const int32_t* __restrict__ filt_idx, const float* __restrict__ thr,
                                                    int32_t* __restrict__ raw_rank, int32_t* __restrict__ filt_rank,
-                                                   int32_t* __restrict__ bad) {
+                                                   int32_t* __restrict__ bad, const int64_t* __restrict__ filt_end) {
   const int row = blockIdx.x;
   if (row >= n) return;
   __shared__ int red[2][256];
@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(256) k_rank_rows(const float* __restrict__ S, 
   const float t = thr[row];
   int cnt = 0, fcnt = 0;
   for (int e = threadIdx.x; e < V; e += 256) cnt += s[e] >= t ? 1 : 0;
-  const int64_t fb = filt_ptr[row], fe = filt_ptr[row + 1];
+  int64_t fb = filt_ptr[row], fe = filt_ptr[row + 1];
+  // a negative, decreasing or overlong range (k_rank_check has flagged it: the call fails) is not walked at all --
+  // nothing may fault before the verdict is read back
+  if (fb < 0 || fe < fb || fe > *filt_end) fb = fe = 0;
   bool oob = false;          // a filter entry out of range fails the call (k_rank_check holds the other checks)
   for (int64_t j = fb + threadIdx.x; j < fe; j += 256) {
     const int fi = filt_idx[j];
@@ -109,6 +112,7 @@ __global__ void __launch_bounds__(256) k_rank_rows(const float* __restrict__ S, 
   }
 }
 
+// (the last entry of filt_ptr is the list's declared length: no range may end beyond it)
 __global__ void k_rank_check(const int32_t* __restrict__ X, int n, int V, int R, const int64_t* __restrict__ filt_ptr,
                              const int32_t* __restrict__ filt_idx, int32_t* __restrict__ bad) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +121,7 @@ __global__ void k_rank_check(const int32_t* __restrict__ X, int n, int V, int R,
   // (the filter entries themselves are range-checked where they are read, 256 lanes wide, in k_rank_rows: one thread
   // walking a list of 1,700 entries here was most of a call's time on the subject side of FB15k-237)
   const bool ok = s >= 0 && s < V && o >= 0 && o < V && r >= 0 && r < R && filt_ptr[row] >= 0 &&
-                  filt_ptr[row] <= filt_ptr[row + 1];
+                  filt_ptr[row] <= filt_ptr[row + 1] && filt_ptr[row + 1] <= filt_ptr[n];
   if (!ok) atomicAdd(bad, 1);
 }
 
@@ -170,7 +174,8 @@ rgcn_status rank_compute(rgcn_ctx* c, const int32_t* X_dev, int64_t N, int predi
       hipLaunchKernelGGL(k_rank_threshold, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->rank_s, c->V, X, n,
                          predict_object, c->rank_thr);
       hipLaunchKernelGGL(k_rank_rows, dim3((unsigned)n), dim3(256), 0, c->stream, c->rank_s, c->V, X, n,
-                         predict_object, filt_ptr + b, filt_idx, c->rank_thr, raw_out + b, filt_out + b, c->rank_bad);
+                         predict_object, filt_ptr + b, filt_idx, c->rank_thr, raw_out + b, filt_out + b, c->rank_bad,
+                         filt_ptr + N);
       RGCN_HIP(c, hipGetLastError());
     }
   }

@@ -46,9 +46,8 @@ ProfScope::~ProfScope() {
   if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, c->stream);
 }
 
-StreamScope::StreamScope(rgcn_ctx* ctx, int k, int in_capture) : c(ctx), saved(ctx->stream), active(false) {
-  static const int cap_forks_env = getenv("RGCN_CAPTURE_FORKS") ? atoi(getenv("RGCN_CAPTURE_FORKS")) : 1;
-  const bool on = c->use_aux || ((in_capture & cap_forks_env) != 0 && c->capturing && c->use_aux_before_capture && c->world == 1);
+StreamScope::StreamScope(rgcn_ctx* ctx, int k, bool in_capture) : c(ctx), saved(ctx->stream), active(false) {
+  const bool on = c->use_aux || (in_capture && c->capturing && c->use_aux_before_capture && c->world == 1);
   if (k < 0 || !on || c->stream != c->main_stream) return;   // nested or disabled: stay on the current stream
   if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess) return;
   if (hipStreamWaitEvent(c->aux[k], c->ev_fork, 0) != hipSuccess) return;
@@ -134,16 +133,15 @@ static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_lis
 // target: workgroups of a split-K launch.  Since the dW_self GEMM runs beside the dH GEMM (the backward layer's pairing)
 // FEWER workgroups pay in the step -- headline 0.555-0.562 ms per step at 256, 0.558-0.568 at 384, 0.565-0.568 at 448,
 // 0.567-0.575 at 512 -- but cost the GEMM itself (alone on the chip 54.6 us at 256, 51 at 448, 48.7 at 512: one workgroup
-// per CU).  The headline shape keeps 512 (the step's gain is ~1 %, inside the box-to-box spread; RGCN_SPLITK_TARGET=256
-// takes it); `narrow` -- 256 -- where the step gains 3-5 %: K >= 32,768 rows (WN18 sizes: 1.128 ms against 1.166) and the
-// basis kind (B = 2: 1.64 against 1.72).  tools/gpu_splitk_ab.sh, tools/gpu_splitk_excl.sh.  The rule reads the model's
+// per CU).  The headline shape keeps 512 (the step's gain is ~1 %, inside the box-to-box spread);
+// `narrow` -- 256 -- where the step gains 3-5 %: K >= 32,768 rows (WN18 sizes: 1.128 ms against 1.166) and the
+// basis kind (B = 2: 1.64 against 1.72).  profiles/r04_*: splitk A/B.  The rule reads the model's
 // dimensions only, one figure for every form of the layer: the split decides the summation order of dW_self, and the forms
 // are held bitwise equal to each other.
 static int auto_split_k(int M, int N, int K, bool narrow = false) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   if (tiles >= 192) return 1;
-  static const int target_env = getenv("RGCN_SPLITK_TARGET") ? atoi(getenv("RGCN_SPLITK_TARGET")) : 0;
-  const int target = target_env > 0 ? target_env : (narrow ? 256 : 512);
+  const int target = narrow ? 256 : 512;
   int s = (target + tiles - 1) / tiles;
   const int max_by_k = (K + 127) / 128;   // at least 128 of K per slab
   if (s > max_by_k) s = max_by_k;
@@ -276,7 +274,7 @@ static void free_all(rgcn_ctx* c) {
       lb.gwself = nullptr;
       if (c->kind == RGCN_KIND_BASIS) lb.grel = nullptr;
     }
-    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wbm); F(lb.wtile);
+    F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wtile);
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
@@ -329,10 +327,6 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   // messages per relation chunk: 48 at minibatch scale; grows with the capacity so that a full-graph
   // context does not cut a popular relation into thousands of chunks
   if (2 * f.max_edges > 65536) c->chunk = 48 * (int)((2 * f.max_edges + 65535) / 65536);
-  if (const char* e = getenv("RGCN_CHUNK")) {
-    const int v = atoi(e);
-    if (v >= 8 && v <= 4096) { c->chunk = v; c->chunk_fixed = true; }
-  }
   if (c->kind == RGCN_KIND_BLOCK) {
     c->nb = f.num_bases;
     if (c->d % c->nb != 0)
@@ -358,17 +352,13 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     // ahead of the long MFMA-bound grid they run beside
     int prio_lo = 0, prio_hi = 0;
     RGCN_HIP(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    const char* e = getenv("RGCN_STREAM_PRIO");
-    const bool use_prio = !(e && atoi(e) == 0);
     // Two high-priority side streams; "side stream 2" is the prefetch stream (created here, normal or low priority):
     // both of its jobs -- the next minibatch's graph prep and the decoder's relation gradient -- are fillers.  A
     // fifth HIP stream would share a hardware queue with one of the other four (ROCm maps streams onto 4 queues by
     // default) and serialise against it: measured, the pipelined encoder step went from 0.60 to 0.97 ms.
-    c->aux_priority = use_prio ? prio_hi : prio_lo;
+    c->aux_priority = prio_hi;
     for (int k = 0; k < 2; ++k) RGCN_HIP(c, acquire_stream(f.device, c->aux_priority, &c->aux[k]));
-    const char* pp = getenv("RGCN_PF_PRIO");
-    const bool pf_low = !(pp && atoi(pp) == 1);
-    c->pf_priority = pf_low ? prio_lo : 0;
+    c->pf_priority = prio_lo;
     RGCN_HIP(c, acquire_stream(f.device, c->pf_priority, &c->pf_stream));
     c->aux[2] = c->pf_stream;
     for (int k = 0; k < kAuxStreams; ++k)
@@ -376,22 +366,15 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   }
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, hipEventDisableTiming));
-  {
-    const char* e = getenv("RGCN_STREAMS");
-    c->use_aux = !(e && atoi(e) == 0);
-    // RGCN_FUSE = 0 / 1 / 2 / 3 picks the form of the block layer (rgcn_set_fusion); all four are bitwise equal.
-    // Default since round 4: 3, the destination-major banded single pass (block_rows.hip) -- no message buffer, weights
-    // through L2: 39-41 us forward / 46-48 backward per layer against 57 / 75 for the two-kernel form 0 at FB15k-237
-    // minibatch size, 0.39 ms against 0.77 per layer pass at the 272,115-edge training graph
-    // (profiles/r04_rowmajor_spmm_ab.md).  Forms 1 (GEMM-epilogue fusion: 87-89 us against 80-83, profiles/r02_fused_
-    // layer_ab.log) and 2 (per-block workgroups + LDS weight table: 125-160 us, profiles/r03_block_spmm_ab.md) stay
-    // opt-in; sharded contexts and the basis kind run form 0 whatever the setting.
-    const char* fu = getenv("RGCN_FUSE");
-    c->fuse = fu ? atoi(fu) : 3;
-    const char* m = getenv("RGCN_GEMM_MODE");
-    const int mode = m ? atoi(m) : 6;
-    c->gemm_mode = (mode == 0 || mode == 3 || mode == 6 || mode == 9) ? mode : 6;
-  }
+  // Block kind: the destination-major banded single pass (block_rows.hip; rgcn_set_fusion 1, the default) -- no message
+  // buffer, weights through L2: 39-41 us forward / 46-48 backward per layer against 57 / 75 for the two-kernel form
+  // (rgcn_set_fusion 0: k_block_msg_* + k_combine, the form every other is held bitwise equal to) at FB15k-237 minibatch
+  // size, 0.39 ms against 0.77 per layer pass at the 272,115-edge training graph (profiles/r04_rowmajor_spmm_ab.md).
+  // Two more forms were built, measured slower and removed in round 5: the combine as the self-loop GEMM's epilogue
+  // (profiles/r02_fused_layer_ab.log) and per-block workgroups with an LDS weight table (profiles/r03_block_spmm_ab.md).
+  c->use_aux = true;
+  c->fuse = 1;
+  c->gemm_mode = 6;
   RGCN_HIP(c, hipEventCreate(&c->t0));
   RGCN_HIP(c, hipEventCreate(&c->t1));
 
@@ -423,7 +406,6 @@ static rgcn_status create_impl(rgcn_ctx* c) {
       RGCN_TRY(dmalloc(c, &lb.grel, 2 * per_dir));
       add_param(c, "W_f" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel, lb.grel, LAYOUT_BLOCK_T);
       add_param(c, "W_b" + sl, {(int64_t)R, c->nb, c->sd, c->sd}, lb.wrel + per_dir, lb.grel + per_dir, LAYOUT_BLOCK_T);
-      if (block_spmm_available(c)) RGCN_TRY(dmalloc(c, &lb.wbm, block_spmm_weight_floats(c)));
       if (c->nb <= 512) RGCN_TRY(dmalloc(c, &lb.wtile, block_rows_weight_floats(c)));
     } else {
       const size_t per_dir = (size_t)c->B * d * d;
@@ -449,7 +431,6 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   RGCN_TRY(dmalloc(c, &c->w_rel, Vd));
   RGCN_TRY(dmalloc(c, &c->g_rel, Vd));
   add_param(c, "W_relation", {(int64_t)V, (int64_t)d}, c->w_rel, c->g_rel, LAYOUT_PLAIN);
-  if (c->fuse < 0 || c->fuse > 3) c->fuse = 0;
   c->H.assign(c->L + 1, nullptr);
   for (int l = 0; l <= c->L; ++l) RGCN_TRY(dmalloc(c, &c->H[l], Vd));
   RGCN_TRY(dmalloc(c, &c->self_buf, Vd));
@@ -556,19 +537,10 @@ static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
   return RGCN_OK;
 }
 
-// The self-loop GEMM takes the combine as its epilogue: block kind, one GPU, split arithmetic (the fp32-MFMA kernel
-// keeps the two-kernel form), 16-byte rows, minibatch scale (no giant rows).
-static bool fused_layer(const rgcn_ctx* c) {
-  return c->fuse == 1 && c->kind == RGCN_KIND_BLOCK && c->world == 1 && c->gemm_mode != 0 && c->d % 4 == 0 && !c->g.giant_on;
-}
-
-// The block layer as ONE pass over the incidence CSR (block_spmm.hip): block kind, one GPU, weight table in LDS.
-static bool spmm_layer(const rgcn_ctx* c) { return c->fuse == 2 && block_spmm_available(c); }
-// ... destination-major, one column band per XCD, weights through L2 (block_rows.hip): block kind, one GPU.
-static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 3 && block_rows_available(c); }   // (any world)
-static rgcn_status single_pass(rgcn_ctx* c, const char* tag, int l, bool backward, const float* X, const CombineArgs& a) {
-  return rows_layer(c) ? block_rows(c, tag, l, backward, X, a) : block_spmm(c, tag, l, backward, X, a);
-}
+// The block layer destination-major in ONE pass over the incidence CSR, one column band per XCD, weights through L2
+// (block_rows.hip): block kind, any world.  Otherwise (rgcn_set_fusion 0, or more blocks than the kernel's lane groups
+// cover) the two-kernel form: relation-major message kernel + k_combine.
+static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 1 && block_rows_available(c); }
 
 // Basis kind: the two direction groups of a batched GEMM over the (row, direction) units of the current graph; the
 // group's extent (rows of A / C, or the depth of dW') is the direction's unit count, read on the device.
@@ -581,24 +553,7 @@ static GemmBatch basis_batch(const rgcn_ctx* c, size_t strideA, size_t strideB, 
   b.limit_on_k = limit_on_k ? 1 : 0;
   return b;
 }
-// share of the 2 V possible units that exist (profile accounting only: the kernels read the counts on the device).
-// Exact while the per-kernel profile is on (one readback per graph), the bound min(messages, 2 V) otherwise.
-static double basis_unit_share(rgcn_ctx* c) {
-  const double cap = 2.0 * c->V;
-  if (c->prof_on && !c->capturing) {
-    if (c->g.units_host < 0) {
-      int32_t n[2] = {0, 0};
-      if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
-      (void)hipStreamSynchronize(c->stream);
-      if (hipMemcpy(&n[0], c->g.unit_ptr + c->V, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
-          hipMemcpy(&n[1], c->g.unit_ptr + 2 * c->V + 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
-        c->g.units_host = (int64_t)n[0] + n[1];
-    }
-    if (c->g.units_host >= 0) return (double)c->g.units_host / cap;
-  }
-  const double M = 2.0 * c->g.E / c->world;
-  return (M < cap ? M : cap) / cap;
-}
+static double basis_unit_share(rgcn_ctx* c) { return basis_units(c) / (2.0 * c->V); }
 
 static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
@@ -607,12 +562,12 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
-  if (spmm_layer(c) || rows_layer(c)) {
+  if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
     // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
     // the incidence CSR (no message buffer)
-    // (sharded run, form 3 only: the self-loop GEMM covers this rank's row shard, the kernel walks the rank's own
-    // messages and writes the PARTIAL pre-activations -- the self-loop term inside the shard only, no relu -- for the
-    // reduce-scatter that follows)
+    // (sharded run: the self-loop GEMM covers this rank's row shard, the kernel walks the rank's own messages and writes
+    // the PARTIAL pre-activations -- the self-loop term inside the shard only, no relu -- for the reduce-scatter that
+    // follows)
     RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d, c->layers[l].wself, d,
                       c->self_buf + (size_t)lo * d, d, 1));
     RGCN_TRY(wait_gather(c));
@@ -623,46 +578,19 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     a.row_lo = lo; a.row_hi = hi;
     a.drop = make_drop(c, l, true);
     a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_fwd" : "block_spmm_fwd", l, false, Hin, a));
-  } else if (fused_layer(c)) {
-    // messages -> ONE kernel: H' = relu(dropout(H.W_self) + sum of the row's messages)
-    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-    GemmEpilogue e;
-    e.mode = 1;
-    e.msg = c->msgbuf; e.row_ptr = c->g.row_ptr;
-    e.relu = l < c->L ? 1 : 0;
-    e.drop = make_drop(c, l, true);
-    e.alg_extra_bytes = 4.0 * d * Mmsg + 4.0 * V;
-    RGCN_TRY(gemm_f32(c, "layer_fwd_fused", true, false, V, d, d, Hin, d, c->layers[l].wself, d, c->H[l], d, 1, &e));
+    RGCN_TRY(block_rows(c, "block_rows_fwd", l, false, Hin, a));
   } else if (c->kind == RGCN_KIND_BLOCK) {
-    // The relational messages (HBM-bound) run beside the self-loop GEMM.  A stream that blocks on another
-    // stream's event resumes ~10 us after the event fires, so the chain that continues (the combine) stays on
-    // the stream of the kernel that finishes LAST: schedule 1 keeps the messages on the main stream and
-    // forks the (shorter) GEMM; schedule 0 is the reverse.
-    static const int fsched = getenv("RGCN_FWD_SCHED") ? atoi(getenv("RGCN_FWD_SCHED")) : 1;
-    if (fsched == 2) {      // everything on the main stream, no fork and no join
-      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
-      RGCN_TRY(wait_gather(c));
-      RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-    } else if (fsched == 1) {
-      {   // self-loop: S = H . W_self  (rows of this rank's shard)
-        StreamScope side(c, 0);
-        RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                          c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
-      }
-      RGCN_TRY(wait_gather(c));
-      RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-    } else {
-      {
-        StreamScope side(c, 0);
-        RGCN_TRY(wait_gather(c));
-        RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-      }
+    // Two-kernel form.  The relational messages (HBM-bound) run beside the self-loop GEMM.  A stream that blocks on
+    // another stream's event resumes ~10 us after the event fires, so the chain that continues (the combine) stays on
+    // the stream of the kernel that finishes LAST: the messages on the main stream, the (shorter) GEMM forked.
+    {   // self-loop: S = H . W_self  (rows of this rank's shard)
+      StreamScope side(c, 0);
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
                         c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
     }
-    if (fsched != 2) RGCN_TRY(stream_join(c, 0));
+    RGCN_TRY(wait_gather(c));
+    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
+    RGCN_TRY(stream_join(c, 0));
     CombineArgs a;
     a.add = nullptr;
     a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
@@ -687,7 +615,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
     const GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
     RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
-                      c->aggbuf, d, 1, nullptr, &gb, basis_unit_share(c)));
+                      c->aggbuf, d, 1, &gb, basis_unit_share(c)));
     RGCN_TRY(stream_join(c, 1));
     CombineArgs a;
     a.add = nullptr;
@@ -740,7 +668,6 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   LayerBufs& lb = c->layers[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
   const bool narrow_dw = c->kind == RGCN_KIND_BASIS || rows >= 32768;       // (see auto_split_k)
-  static const int sched = getenv("RGCN_BWD_SCHED") ? atoi(getenv("RGCN_BWD_SCHED")) : 2;
 
   // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
   CombineArgs a;
@@ -762,117 +689,69 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(stream_join(c, 0));
     c->dw_pending = false;
   }
-  if (spmm_layer(c) || rows_layer(c)) {
-    // weight gradients of the relations (dW_r = sum n g (x) x, relation-major, two row gathers per message) on side
-    // stream 0 beside the self-loop GEMMs; the row gradients come from the single-pass kernel behind G = dS . W_self^T
-    // One GPU: everything of the layer on the main stream.  The row-gradient kernel needs the dH GEMM's product, so the
-    // layer's chain has nothing to overlap with, and the two independent kernels (relation-weight gradients, dW_self)
-    // beside it only stretch it: 0.589-0.599 ms per step serial against 0.595-0.610 with them on side streams
-    // (tools/gpu_sched_ab.sh, three boxes).  Sharded runs keep the side streams (the all-gather rides on one).
-    // At the training graph's size (272,115 edges: the message-gradient kernel is five GEMMs long) the side stream
-    // pays again -- 2.50 ms per step against 2.54 (tools/gpu_traingraph_ab.sh) -- so the default goes by the graph:
-    // RGCN_ROWS_SERIAL unset: main stream up to 65,536 edges; 1 / 0 force either.
-    static const int rows_serial_env = getenv("RGCN_ROWS_SERIAL") ? atoi(getenv("RGCN_ROWS_SERIAL")) : -1;
-    static const int corun_env = getenv("RGCN_GEMM_CORUN") ? atoi(getenv("RGCN_GEMM_CORUN")) : 1;
-    const bool serial = c->world == 1 && (rows_serial_env < 0 ? c->g.E <= 65536 : rows_serial_env != 0);
-    const bool aux_saved = c->use_aux;
-    // (a captured step is a chain -- rgcn_capture_begin -- with two exceptions: the decoder's preparation and this
-    // pairing, RGCN_CAPTURE_FORKS bit 1: 1.004-1.023 ms per replayed train step against 1.029-1.033 without it; the
-    // decoder's relation-gradient reduce forked as well, bit 2: 1.015-1.041 -- tools/gpu_capture_forks_ab.sh)
-    const bool cap_fork = c->capturing && c->use_aux_before_capture && c->world == 1 && serial;
-    const bool corun = corun_env != 0 && (aux_saved || cap_fork) && c->world == 1;
-    // RGCN_BWD_LATE_DW (default 1): the message-gradient kernel of the relation weights is forked BEHIND the dH GEMM and
-    // runs beside the row-gradient kernel -- two gather kernels, each bound by the latency of its gathers and neither by
-    // bytes, share the chip better than either does with a GEMM -- and is joined at the end of the layer: 0.553-0.556 ms
-    // per step against 0.560-0.566 with it in front of the GEMMs on the main stream; joined a layer later: 0.563-0.568
-    // (tools/gpu_env_ab.sh).  Captured steps keep the chain + GEMM pairing.
-    static const int late_dw_env = getenv("RGCN_BWD_LATE_DW") ? atoi(getenv("RGCN_BWD_LATE_DW")) : 1;
-    static const int cap_forks_bits = getenv("RGCN_CAPTURE_FORKS") ? atoi(getenv("RGCN_CAPTURE_FORKS")) : 1;
-    const bool late_dw = late_dw_env != 0 && corun && serial && rows_layer(c) &&
-                         (c->capturing ? (cap_fork && (cap_forks_bits & 4) != 0) : aux_saved);
-    if (late_dw) {
+  // the three dense / relation-weight pieces every block schedule below is made of
+  auto self_dw = [&]() {      // dW_self = H_in^T . dS   (split-K)
+    return gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
+                    lb.gwself, d, auto_split_k(d, d, rows, narrow_dw));
+  };
+  auto self_dh = [&]() {      // G = dS . W_self^T
+    return gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
+                    c->self_buf + (size_t)lo * d, d, 1);
+  };
+  if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
+    // Row gradients: the single-pass kernel behind G = dS . W_self^T.  Relation-weight gradients (dW_r = sum n g (x) x,
+    // relation-major, two row gathers per message): k_block_msg_bwd<dW only> + its slab reduce.  ONE schedule per
+    // situation, each the measured best of round 4's A/Bs (profiles/r04_rowmajor_spmm_ab.md, r04_block_forms_ab.txt):
+    //   minibatch scale, one GPU, side streams on:  dW_self forked BEFORE dH is launched (MFMA beside MFMA: the second
+    //       GEMM fills the slots the first leaves idle, 456 workgroups on 512, and its tail), the relation-weight kernels
+    //       forked BEHIND dH, beside the row-gradient kernel (two gather kernels share the chip better than either does
+    //       with a GEMM), joined at the end of the layer: 0.553-0.556 ms per step against 0.597-0.599 as a chain;
+    //   the same inside a capture (a captured step is a chain, rgcn_capture_begin) or with the side streams off: the
+    //       chain, with the one fork a replayed graph gains from -- the slab reduce + dW_self beside dH;
+    //   full-graph scale or a sharded run: the relation-weight kernels on side stream 0 from the start of the layer
+    //       (at 272,115 edges they are five GEMMs long; a sharded run's all-gather rides on side stream 1), joined
+    //       before the next layer overwrites D.
+    const bool minibatch = c->world == 1 && c->g.E <= 65536;
+    if (minibatch && c->use_aux) {
       {
-        StreamScope side(c, 1, 1);
-        RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                          lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
+        StreamScope side(c, 1);
+        RGCN_TRY(self_dw());
       }
-      RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                        c->self_buf + (size_t)lo * d, d, 1));
+      RGCN_TRY(self_dh());
       {
-        StreamScope side(c, 0, 4);
+        StreamScope side(c, 0);
         RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
         RGCN_TRY(block_dw_reduce(c, l));
       }
-      RGCN_TRY(single_pass(c, "block_rows_bwd", l, true, c->bwd_D, a));
+      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
       RGCN_TRY(stream_join(c, 0));
-      c->dw_pending = false;
+    } else if (minibatch) {
+      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
+      {
+        StreamScope side(c, 1, /*in_capture=*/true);
+        RGCN_TRY(block_dw_reduce(c, l));
+        RGCN_TRY(self_dw());
+      }
+      RGCN_TRY(self_dh());
+      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
     } else {
-      struct AuxRestore {           // (an early error return must not leave the side streams switched off)
-        rgcn_ctx* c; bool v;
-        ~AuxRestore() { c->use_aux = v; }
-      } restore{c, aux_saved};
-      if (serial) c->use_aux = false;
       {
         StreamScope side(c, 0);
         RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
         RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-        if (!(corun && serial)) RGCN_TRY(block_dw_reduce(c, l));     // (behind its producer, on whichever stream that is)
+        RGCN_TRY(block_dw_reduce(c, l));
         c->dw_pending = side.active;
       }
-      if (corun) {
-        // MFMA beside MFMA is the pairing that pays: dW_self = H^T.dS is forked to side stream 1 BEFORE dH = dS.W^T is
-        // launched, so the second GEMM fills the CU slots the first leaves idle (456 workgroups on 512) and its tail; the
-        // slab reduce of the relation-weight gradients (small, latency-bound) leads that side stream and runs under the
-        // dH GEMM's start.  0.566-0.574 ms per step against 0.580-0.587 with only the GEMMs paired and 0.597-0.599 with
-        // everything one behind the other (tools/gpu_corun_ab.sh); the message-gradient kernel itself beside the GEMMs
-        // (either end of the side stream) loses 8-10 us again.
-        c->use_aux = aux_saved;
-        {
-          StreamScope side(c, 1, 1);
-          if (serial) RGCN_TRY(block_dw_reduce(c, l));
-          RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                            lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-        }
-        RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                          c->self_buf + (size_t)lo * d, d, 1));
-      } else {
-        RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                          c->self_buf + (size_t)lo * d, d, 1));
-        {
-          StreamScope side(c, 1);
-          RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                            lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-        }
+      {
+        StreamScope side(c, 1);
+        RGCN_TRY(self_dw());
       }
-      c->use_aux = aux_saved;
+      RGCN_TRY(self_dh());
       RGCN_TRY(wait_gather(c));
-      RGCN_TRY(single_pass(c, rows_layer(c) ? "block_rows_bwd" : "block_spmm_bwd", l, true, c->bwd_D, a));
+      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
     }
-  } else if (fused_layer(c)) {
-    // message gradients -> ONE kernel: D' = (dS.W_self^T + sum of the row's message
-    // gradients) * relu'(H_in), dS' = D' * dropout; the per-relation dW reduction and the dW_self GEMM trail on the
-    // side streams
-    RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
-    {
-      StreamScope side(c, 0);
-      RGCN_TRY(block_dw_reduce(c, l));
-    }
-    {
-      StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-    }
-    GemmEpilogue e;
-    e.mode = 2;
-    e.msg = c->msgbuf; e.row_ptr = c->g.row_ptr;
-    e.gate = a.gate; e.out2 = a.out2; e.drop2 = a.drop2;
-    e.alg_extra_bytes = 4.0 * d * ((a.out2 ? 2.0 : 1.0) * V + Mmsg) + 4.0 * V;
-    RGCN_TRY(gemm_f32(c, "layer_bwd_fused", true, true, V, d, d, c->bwd_dS, d, lb.wself, d, a.out, d, 1, &e));
   } else if (c->kind == RGCN_KIND_BLOCK) {
-    {   // the relational gradient kernels (HBM-bound) run on a side stream beside the self-loop GEMMs
-        // (MFMA-bound); two MFMA-bound grids side by side only interleave (measured: no gain).  (Tried: the message
-        // kernel on the main stream and both GEMMs on side streams, so that the main stream never waits across
-        // streams -- 0.655 ms per step against 0.62.)
+    {   // two-kernel form: the relational gradient kernels (HBM-bound) on a side stream beside the self-loop GEMMs
       StreamScope side(c, 0);
       RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
@@ -881,18 +760,10 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
       if (side.active) RGCN_HIP(c, hipEventRecord(c->ev_join[0], c->aux[0]));
       RGCN_TRY(block_dw_reduce(c, l));
     }
-    if (sched == 0) {
+    RGCN_TRY(self_dh());
+    {   // dW_self on side stream 1, queued behind the dH GEMM
       StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
-    }
-    // G = dS . W_self^T
-    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                      c->self_buf + (size_t)lo * d, d, 1));
-    if (sched == 2) {   // dW_self = H_in^T . dS on side stream 1, queued behind the dH GEMM
-      StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
+      RGCN_TRY(self_dw());
     }
     if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
     a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
@@ -900,9 +771,6 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     a.long_rows = c->g.long_rows;
     a.nlong = c->g.nlong;
     RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
-    if (sched == 1)
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
   } else {
     const int Bd = c->B * d;
     // The upstream rows of the units, compacted like Zc (the row operand of dZ, the depth operand of dW')
@@ -914,18 +782,16 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     // other's idle CU slots and tails.
     {
       StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d,
-                        c->bwd_dS + (size_t)lo * d, d, lb.gwself, d, auto_split_k(d, d, rows, narrow_dw)));
+      RGCN_TRY(self_dw());
       // dW'_dir = Zc_dir^T . Dc_dir   ([B.d, units] x [units, d], split over the units; two groups)
       const GemmBatch gk = basis_batch(c, (size_t)V * Bd, (size_t)V * d, (size_t)Bd * d, true);
       RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, Bd, d, V, c->zsave[l], Bd, c->aggbuf, d, lb.grel, d,
-                        auto_split_k(2 * Bd, d, V), nullptr, &gk, basis_unit_share(c)));
+                        auto_split_k(2 * Bd, d, V), &gk, basis_unit_share(c)));
     }
-    RGCN_TRY(gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                      c->self_buf + (size_t)lo * d, d, 1));
+    RGCN_TRY(self_dh());
     // dZc_dir = Dc_dir . W'_dir^T   ([units, d] x [d, B.d], two groups)
     const GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
-    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, nullptr, &gm,
+    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, &gm,
                       basis_unit_share(c)));
     RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
     RGCN_TRY(basis_backward_gather(c, l, c->msgbuf2, a, true));
@@ -1504,9 +1370,9 @@ rgcn_status rgcn_capture_begin(rgcn_ctx* c) {
   // path is exercised with device-side stand-in collectives of several ranks on ONE GPU only
   // (tests/test_gpu_multiprocess.py::test_captured_sharded_train_step); real librccl kernels inside a capture have never
   // run here (no multi-GPU box), so it stays EXPERIMENTAL and opt-in: RGCN_CAPTURE_SHARDED=1.
-  if (c->world > 1 && !(getenv("RGCN_CAPTURE_SHARDED") && atoi(getenv("RGCN_CAPTURE_SHARDED")) == 1))
+  if (c->world > 1 && knob("RGCN_CAPTURE_SHARDED", 0) != 1)
     RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "capture on a sharded context is experimental (never run against real RCCL on "
-                                       "several GPUs): set RGCN_CAPTURE_SHARDED=1 to enable it");
+                                       "several GPUs): the devtools build enables it with RGCN_CAPTURE_SHARDED=1");
   RGCN_TRY(sync_all(c));
   if (!c->replay_counter) {
     RGCN_HIP(c, hipMalloc((void**)&c->replay_counter, sizeof(uint64_t)));
@@ -1578,7 +1444,7 @@ rgcn_status rgcn_graph_launch(rgcn_ctx* c, int32_t graph_id) {
   RGCN_HIP(c, hipGraphLaunch(c->graphs[graph_id], c->main_stream));
   c->fwd_done = true;       // the replayed steps leave activations / gradients of their last step behind
   c->weights_version += 1;  // a replayed train step moved the weights behind the host's back: derived weight tables
-                            // (block_spmm / block_rows) built before the replay are stale for uncaptured passes
+                            // (block_rows) built before the replay are stale for uncaptured passes
   return RGCN_OK;
 }
 
@@ -1768,7 +1634,7 @@ rgcn_status rgcn_set_overlap(rgcn_ctx* c, int32_t on) {
 
 rgcn_status rgcn_set_fusion(rgcn_ctx* c, int32_t mode) {
   RGCN_NEED(c);
-  if (mode < 0 || mode > 3) RGCN_FAIL(c, RGCN_ERR_INVALID, "fusion mode must be 0, 1, 2 or 3");
+  if (mode != 0 && mode != 1) RGCN_FAIL(c, RGCN_ERR_INVALID, "fusion mode must be 0 (two kernels) or 1 (single pass)");
   c->fuse = mode;
   return RGCN_OK;
 }

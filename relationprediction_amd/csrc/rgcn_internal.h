@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -13,6 +14,17 @@
 #include "../../include/rgcn.h"
 
 namespace rgcn {
+
+// Experiment knobs exist in the devtools build only (librgcn_devtools.so, -DRGCN_DEVTOOLS: tools/ and a few tests); the
+// product library reads no tuning variable from the environment and runs ONE configuration, the default.
+#ifdef RGCN_DEVTOOLS
+inline int knob(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+#else
+constexpr int knob(const char*, int dflt) { return dflt; }
+#endif
 
 // ---------------------------------------------------------------- error plumbing
 void set_global_error(const std::string& s);
@@ -109,24 +121,6 @@ __device__ __forceinline__ float drop_factor(const DropSpec& ds, const DropKey& 
 __device__ __forceinline__ float drop_factor(const DropSpec& ds, size_t idx) { return drop_factor(ds, drop_key(ds), idx); }
 #endif
 
-// What k_combine does behind the self-loop GEMM, fused into the GEMM's own epilogue (gemm_bf16x3.hip): the product
-// tile never goes to HBM and back.  Reference: MessageGcn.compute_vertex_embeddings + ConcatGcn.combine_messages
-// (message_gcn.py:60-64, gcn_basis_concat.py:69-83) forward, their tf.gradients backward.
-//   mode 1 (forward):  out = relu?( dropout(A.B) + sum over the row's message slots )
-//   mode 2 (backward): out = ( A.B + sum over the row's message slots ) * (gate > 0);  out2 = out * dropout2
-// Rows with more than kLongRow slots are summed by the whole workgroup, in k_combine's order.
-struct GemmEpilogue {
-  int32_t mode = 0;
-  const float* msg = nullptr;         // message rows [slots, d], incidence order
-  const int32_t* row_ptr = nullptr;   // [V+1]
-  const float* gate = nullptr;
-  float* out2 = nullptr;
-  int32_t relu = 0;
-  DropSpec drop;                      // mode 1: on the product
-  DropSpec drop2;                     // mode 2: on out2
-  double alg_extra_bytes = 0;         // algorithmic bytes the epilogue adds to the GEMM's own (profile accounting)
-};
-
 // ---------------------------------------------------------------- profiling records
 struct ProfRec {
   const char* name;
@@ -168,10 +162,6 @@ struct LayerBufs {
   float* gwself = nullptr;
   float* bias = nullptr;    // [d], unused by the math
   float* gbias = nullptr;
-  // BLOCK, single-pass layer kernel (block_spmm.hip): block-major copy of wrel, [nb][2R][sd*sd padded to 4], and the
-  // weights version it was built from
-  float* wbm = nullptr;
-  uint64_t wbm_version = ~0ull;
   // BLOCK, destination-major banded layer kernel (block_rows.hip): band-tiled copy of wrel,
   // [2R][8 bands][ceil(sd*sd/4)][GW lanes][4], allocated at first use
   float* wtile = nullptr;
@@ -342,10 +332,9 @@ struct rgcn_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[rgcn::kAuxStreams] = {nullptr, nullptr, nullptr};
   bool use_aux = true;
   bool aux_dirty[rgcn::kAuxStreams] = {false, false, false};   // something was forked onto side stream k since its last join
-  // block kind, one GPU: 0 = message kernel + k_combine (two kernels, [2E,d] message buffer), 1 = self-loop GEMM with
-  // the combine as its epilogue, 2 = single-pass block SpMM (block_spmm.hip; no message buffer at all), 3 = the
-  // destination-major banded single-pass layer (block_rows.hip; no message buffer, weights through L2)
-  int fuse = 0;
+  // block kind: 0 = message kernel + k_combine (two kernels, [2E,d] message buffer), 1 = the destination-major banded
+  // single-pass layer (block_rows.hip; no message buffer, weights through L2)
+  int fuse = 1;
   uint64_t weights_version = 1;           // bumped whenever a parameter value changes (set_param, Adam)
   bool dw_pending = false;                // a dW-only message-gradient kernel of the previous backward layer is still on side stream 0
   std::string err;
@@ -391,7 +380,6 @@ struct rgcn_ctx {
   uint8_t* readback_host = nullptr;      // 32 pinned bytes: rgcn_get_loss fetches the loss and the error flag with one wait
   hipEvent_t stage_done[kStageSlots] = {};
   int stage_next = 0;
-  bool chunk_fixed = false;              // RGCN_CHUNK in the environment pins the chunk size
   int chunk = 48;                        // messages per relation chunk (capacity-scaled upper bound; GraphBufs::chunk is per graph)
   int gemm_mode = 0;                     // 0: fp32 MFMA; 3/6/9: bf16 split with that many partial products
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
@@ -441,7 +429,7 @@ struct StreamScope {
   bool active;
   // in_capture: the fork is also taken while a step is being captured (a captured step is otherwise one chain: the
   // side streams are switched off for the capture, rgcn_capture_begin)
-  StreamScope(rgcn_ctx* ctx, int k, int in_capture = 0);       // in_capture: bit of RGCN_CAPTURE_FORKS that allows it
+  StreamScope(rgcn_ctx* ctx, int k, bool in_capture = false);
   ~StreamScope();
 };
 rgcn_status stream_join(rgcn_ctx* c, int k);
@@ -498,14 +486,12 @@ struct GemmBatch {
 // `slab` ([group][split_k][M][N]) and reduces them into C deterministically.
 rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, int N, int K,
                      const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                     int split_k, const GemmEpilogue* epi = nullptr, const GemmBatch* batch = nullptr,
-                     double prof_scale = 1.0);
+                     int split_k, const GemmBatch* batch = nullptr, double prof_scale = 1.0);
 
 // gemm_bf16x3.hip: the same contraction on the bf16 matrix cores (exact 3-way operand split)
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int k_per_split, int splits, int swizzle, int vecC, const GemmEpilogue* epi = nullptr,
-                              const GemmBatch* batch = nullptr);
+                              int k_per_split, int splits, int swizzle, int vecC, const GemmBatch* batch = nullptr);
 
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);
@@ -516,13 +502,7 @@ rgcn_status block_dw_reduce(rgcn_ctx* c, int layer);
 rgcn_status block_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst, int R);
 rgcn_status block_from_device_layout(rgcn_ctx* c, const float* src, float* host_layout_dev, int R);
 
-// ---- block_spmm.hip: the block layer in ONE pass per direction (gather, sd x sd products, segmented row sums, self-loop
-// term, dropout, relu / relu'), no message buffer
 struct CombineArgs;
-bool block_spmm_available(const rgcn_ctx* c);
-size_t block_spmm_weight_floats(const rgcn_ctx* c);
-rgcn_status block_spmm(rgcn_ctx* c, const char* tag, int layer, bool backward, const float* X, const CombineArgs& ca);
-
 // ---- block_rows.hip: the block layer destination-major in ONE pass per direction, one column band per XCD, weights
 // through L2 (no LDS table, no message buffer); bitwise equal to the two-kernel form
 bool block_rows_available(const rgcn_ctx* c);
@@ -535,6 +515,7 @@ struct CombineArgs;
 rgcn_status basis_backward_gather(rgcn_ctx* c, int layer, const float* dZ, const CombineArgs& ca,
                                   bool with_messages);
 rgcn_status basis_dcoef(rgcn_ctx* c, int layer, const float* Hin, const float* dZ);
+double basis_units(rgcn_ctx* c);      // (row, direction) units of the current graph (profile accounting)
 // Dc[dir][i][:] = D[row of unit i of direction dir][:]  (the compacted upstream rows, [2][V][d])
 rgcn_status basis_gather_units(rgcn_ctx* c, const float* D, float* Dc);
 rgcn_status basis_to_device_layout(rgcn_ctx* c, const float* host_layout_dev, float* dst);

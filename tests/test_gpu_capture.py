@@ -197,11 +197,18 @@ def test_capture_on_a_sharded_context_needs_its_communicator(native):
     """BASELINE config 5 asks for a captured train step on 8 GPUs.  Capture on a world > 1 context is EXPERIMENTAL (the
     collectives inside the graph are exercised with stand-in collectives on one GPU only,
     test_gpu_multiprocess.py::test_captured_sharded_train_step) and opt-in: refused by name without
-    RGCN_CAPTURE_SHARDED=1; with it, a step without a communicator still fails inside the capture as it does outside,
-    and the capture can be ended."""
+    RGCN_CAPTURE_SHARDED=1 -- a knob of the devtools build; the product library refuses whatever the environment says --;
+    with it, a step without a communicator still fails inside the capture as it does outside, and the capture can be
+    ended."""
     import os
-    eng = native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2)
     old = os.environ.pop("RGCN_CAPTURE_SHARDED", None)
+    os.environ["RGCN_CAPTURE_SHARDED"] = "1"
+    with native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2) as prod:       # product library
+        with pytest.raises(native.RgcnError) as err:
+            prod.capture_begin()
+        assert "RGCN_CAPTURE_SHARDED=1" in str(err.value)
+    os.environ.pop("RGCN_CAPTURE_SHARDED", None)
+    eng = native.Engine(40, 4, 8, 1, "block", 2, max_edges=16, rank=0, world=2, devtools=True)
     try:
         tri = eng.to_device(np.array([[0, 1, 2], [3, 0, 4]], dtype=np.int32))
         dc = eng.to_device(np.zeros((40, 8), dtype=np.float32))

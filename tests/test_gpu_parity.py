@@ -572,9 +572,10 @@ def test_float64_tie_break(native, name, gemm_mode):
 
 # ------------------------------------------------------------------ relation sharding on one GPU
 @pytest.mark.parametrize("world", [2, 4])
-def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4):
+def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4, fusion=1, partials=None):
     """world ranks as separate contexts on ONE device; the all-reduce is done by the test through
-    read_buffer/write_buffer (the collective's test double).  Result must equal the unsharded run."""
+    read_buffer/write_buffer (the collective's test double).  Result must equal the unsharded run.
+    partials (a list): every rank's PARTIAL pre-activation / gradient buffer of every layer is appended to it."""
     V, R, d, L, nb, E = 90, 10, 20, 2, 4, 600
     params, triples, masks, dcodes = make_case(V, R, d, L, kind, nb, E, seed=12)
     oacts, ograds = oracle.encoder_step(params, triples, V, L, kind, dcodes, dropout_masks=masks)
@@ -583,6 +584,7 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4)
     engs = [native.Engine(V, R, d, L, kind, nb, max_edges=E, rank=r, world=world) for r in range(world)]
     try:
         for e in engs:
+            e.set_fusion(fusion)
             e.set_params(params)
             e.set_relation_owner(owner)
             e.set_graph(triples)
@@ -590,7 +592,10 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4)
         for l in range(1, L + 1):
             for e in engs:
                 e.forward_layer_partial(l)
-            total = sum(e.read_buffer(native.BUF_EXCHANGE) for e in engs)
+            parts = [e.read_buffer(native.BUF_EXCHANGE) for e in engs]
+            if partials is not None:
+                partials.extend(parts)
+            total = sum(parts)
             for e in engs:
                 e.write_buffer(native.BUF_EXCHANGE, total)
                 e.forward_layer_finish(l)
@@ -602,7 +607,10 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4)
         for l in range(L, 0, -1):
             for e in engs:
                 e.backward_layer_partial(l)
-            tot = sum(e.read_buffer(native.BUF_EXCHANGE) for e in engs)
+            parts = [e.read_buffer(native.BUF_EXCHANGE) for e in engs]
+            if partials is not None:
+                partials.extend(parts)
+            tot = sum(parts)
             totw = sum(e.read_buffer(native.BUF_DSELF_EXCHANGE) for e in engs)
             for e in engs:
                 e.write_buffer(native.BUF_EXCHANGE, tot)
@@ -612,6 +620,8 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4)
             e.backward_end()
         for r, e in enumerate(engs):
             g = e.get_grads()
+            if partials is not None:
+                partials.append(g)
             for name in ["W_emb", "b_emb", "W_self1", "W_self2"]:
                 assert_close(g[name], ograds[name], rel=2e-4, name="rank%d %s" % (r, name))
             per_rel = ["W_f1", "W_b1", "W_f2", "W_b2"] if kind == "block" else ["C_f1", "C_b1", "C_f2", "C_b2"]
@@ -632,6 +642,23 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4)
 
 def test_relation_sharding_basis(native):
     test_relation_sharding_with_host_exchange(native, 2, kind="basis", nb=3)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_single_pass_equals_the_sharded_two_kernel_form(native, world):
+    """Relation-sharded contexts run the destination-major single pass (rgcn_set_fusion 1) by default: every rank's
+    partial pre-activations, partial row gradients and final gradients are BITWISE those of the two-kernel form
+    (rgcn_set_fusion 0) on the same shard, layer by layer."""
+    a, b = [], []
+    test_relation_sharding_with_host_exchange(native, world, fusion=1, partials=a)
+    test_relation_sharding_with_host_exchange(native, world, fusion=0, partials=b)
+    assert len(a) == len(b) and len(a) == 2 * 2 * world + world
+    for x, y in zip(a, b):
+        if isinstance(x, dict):
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+        else:
+            np.testing.assert_array_equal(x, y)
 
 
 def test_rccl_single_rank_communicator(native):
@@ -655,17 +682,13 @@ def test_rccl_single_rank_communicator(native):
                                              (2000, 30, 500, 100, 6000, 4), (1100, 7, 24, 3, 9000, 2), (600, 4, 9, 9, 3000, 1),
                                              (400, 6, 170, 170, 3000, 2), (350, 5, 300, 300, 2500, 1)])
 @pytest.mark.parametrize("gen_dropout", [False, True])
-@pytest.mark.parametrize("mode", [1, 2, 3])
-def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, hubs, gen_dropout, mode):
-    """rgcn_set_fusion: mode 1, the self-loop GEMM with the combine as its epilogue, mode 2, the single-pass block
-    SpMM (gather + sd x sd products + segmented row sums + self-loop term + dropout + relu in ONE kernel per layer and
-    direction, no message buffer), and mode 3, the destination-major banded single pass (block_rows.hip: one column band
-    per XCD, a lane group per (row, band), long rows by one wavefront each; group widths 8 / 16 / 32 / 64 lanes at
-    nb <= 64 / 100 / 170 / 300) against mode 0 (message kernel + k_combine) -- same products, same summation order:
-    every activation and every gradient BITWISE equal, with hub rows (more than 32 slots: eight interleaved lanes),
-    rows spanning several slot tiles, injected and generated dropout, an empty graph, sd in {1, 3, 4, 5, 8}"""
-    if mode == 1 and d % 4 != 0:
-        pytest.skip("the GEMM-epilogue form needs 16-byte rows")
+def test_single_pass_layer_equals_the_two_kernel_form(native, V, R, d, nb, E, hubs, gen_dropout):
+    """rgcn_set_fusion 1 (default), the destination-major banded single pass (block_rows.hip: gather + sd x sd products +
+    segmented row sums + self-loop term + dropout + relu in ONE kernel per layer and direction, no message buffer; one
+    column band per XCD, a lane group per (row, band), long rows by one wavefront each; group widths 8 / 16 / 32 / 64
+    lanes at nb <= 64 / 100 / 170 / 300) against form 0 (message kernel + k_combine) -- same products, same summation
+    order: every activation and every gradient BITWISE equal, with hub rows (more than 32 slots: eight interleaved
+    lanes), rows spanning several slot tiles, injected and generated dropout, an empty graph, sd in {1, 3, 4, 5, 8}"""
     params, triples, masks, dcodes = make_case(V, R, d, 2, "block", nb, E, seed=V + E)
     if hubs:
         rng = np.random.RandomState(1)
@@ -673,7 +696,7 @@ def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, h
             idx = rng.choice(E, size=min(E // 4, 1500 if V == 1100 else 300), replace=False)
             triples[idx, 2 if h % 2 == 0 else 0] = h
     out = []
-    for fuse in (mode, 0):
+    for fuse in (1, 0):
         eng = native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=max(E, 1))
         try:
             eng.set_fusion(fuse)
@@ -689,9 +712,9 @@ def test_fused_layer_kernel_equals_the_two_kernel_form(native, V, R, d, nb, E, h
     for l in range(3):
         np.testing.assert_array_equal(fa[l], ua[l], err_msg="H%d" % l)
     for k in fg:
-        if k == "b_emb" and mode == 3:
-            # form 3 sums the columns of dL/dH0 inside the kernel that writes it (per workgroup, then k_colsum_final's
-            # fixed order): the same terms in another, equally fixed, order
+        if k == "b_emb":
+            # the single pass sums the columns of dL/dH0 inside the kernel that writes it (per workgroup, then
+            # k_colsum_final's fixed order): the same terms in another, equally fixed, order
             scale = np.abs(ug["W_emb"]).sum(axis=0).max() + 1e-30
             assert np.abs(fg[k] - ug[k]).max() <= 2e-6 * scale, k
             continue
@@ -727,15 +750,14 @@ def test_bias_gradient_from_the_row_kernel_is_the_same_in_every_engine(native):
     assert np.abs(outs[0]["b_emb"] - want).max() <= 2e-6 * scale
 
 
-def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
-    """mode 2 on a graph with giant rows (more than 65,536 messages, a 6,000-slot hub: the piece-by-piece order of the
-    giant-row cut) still equals mode 0 bitwise in the forward pass and the gradients; a relation count whose weight
-    table does not fit in LDS silently runs the two-kernel form (same results by construction)."""
+def test_single_pass_block_layer_at_full_graph_scale(native):
+    """the single pass on a graph with giant rows (more than 65,536 messages, a 6,000-slot hub: the piece-by-piece order
+    of the giant-row cut) still equals the two-kernel form bitwise in the forward pass and the gradients."""
     V, R, d, nb, E = 3000, 20, 20, 4, 40000
     params, triples, masks, dcodes = make_case(V, R, d, 2, "block", nb, E, seed=5)
     triples[np.random.RandomState(2).choice(E, 6000, replace=False), 2] = 7
     out = []
-    for fuse in (2, 3, 0):
+    for fuse in (1, 0):
         with native.Engine(V, R, d, 2, "block", nb, keep_prob=0.8, max_edges=E) as eng:
             eng.set_fusion(fuse)
             eng.set_params(params)
@@ -744,28 +766,15 @@ def test_single_pass_block_layer_at_full_graph_scale_and_fallback(native):
             codes = eng.codes()
             eng.backward(dcodes)
             out.append((codes, eng.get_grads()))
-    for form in (0, 1):
-        np.testing.assert_array_equal(out[form][0], out[2][0])
-        for k in out[form][1]:
-            if k == "b_emb" and form == 1:       # form 3: column sums from the row-gradient kernel (giant rows included)
-                scale = np.abs(out[2][1]["W_emb"]).sum(axis=0).max() + 1e-30
-                assert np.abs(out[form][1][k] - out[2][1][k]).max() <= 2e-6 * scale
-                got = out[form][1]["W_emb"].astype(np.float64).sum(axis=0)
-                assert np.abs(out[form][1][k] - got).max() <= 2e-6 * scale
-                continue
-            np.testing.assert_array_equal(out[form][1][k], out[2][1][k], err_msg=k)
-    # 2R x sd^2 floats = 2 * 3000 * 25 * 4 B = 600 KB: no LDS table -> form 0 under the hood, still correct
-    V, R, d, nb, E = 200, 3000, 10, 2, 500
-    params, triples, masks, dcodes = make_case(V, R, d, 1, "block", nb, E, seed=6)
-    res = []
-    for fuse in (2, 0):
-        with native.Engine(V, R, d, 1, "block", nb, keep_prob=0.8, max_edges=E) as eng:
-            eng.set_fusion(fuse)
-            eng.set_params(params)
-            eng.set_graph(triples)
-            eng.forward(train=False)
-            res.append(eng.codes())
-    np.testing.assert_array_equal(res[0], res[1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        if k == "b_emb":       # column sums from the row-gradient kernel (giant rows included)
+            scale = np.abs(out[1][1]["W_emb"]).sum(axis=0).max() + 1e-30
+            assert np.abs(out[0][1][k] - out[1][1][k]).max() <= 2e-6 * scale
+            got = out[0][1]["W_emb"].astype(np.float64).sum(axis=0)
+            assert np.abs(out[0][1][k] - got).max() <= 2e-6 * scale
+            continue
+        np.testing.assert_array_equal(out[0][1][k], out[1][1][k], err_msg=k)
 
 
 def test_training_graph_scale_properties(native):

@@ -74,7 +74,7 @@ def _decoder_grads(native, V, R, d, nb, X, Y, lines, top_dropout=0.0, seed=3):
     params, triples, _, _ = make_case(V, R, d, L, "block", nb, 4 * V, seed=seed)
     old = os.environ.get("RGCN_DEC_LINES")
     os.environ["RGCN_DEC_LINES"] = "1" if lines else "0"
-    eng = native.Engine(V, R, d, L, "block", nb, max_edges=len(triples))
+    eng = native.Engine(V, R, d, L, "block", nb, max_edges=len(triples), devtools=True)   # RGCN_DEC_LINES: devtools build only
     try:
         eng.set_params(params)
         eng.set_graph(triples)

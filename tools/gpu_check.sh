@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2
 rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing"
-timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 600 -p no:cacheprovider "$@" > gpurun_out/pytest_gpu_$TAG.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 1200 -p no:cacheprovider --durations=8 "$@" > gpurun_out/pytest_gpu_$TAG.log 2>&1
 echo "pytest exit $?"
 tail -n 40 gpurun_out/pytest_gpu_$TAG.log
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err

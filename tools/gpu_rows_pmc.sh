@@ -9,7 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
 CMD="python bench.py --workload $WL --steps 6 --warmup 2 --cpu-steps 0 --no-kernel-profile --no-extra-workloads --no-fp32-reference --no-live-traffic"
-export RGCN_STREAMS=0 RGCN_BENCH_PREFETCH=0 RGCN_FUSE=3 "$@"
+export RGCN_STREAMS=0 RGCN_BENCH_PREFETCH=0 "$@"
 pass() { n=$1; shift; timeout 120 rocprofv3 --pmc "$@" -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1; python tools/pmc_summary.py $OUT/$n/${n}_results.db "k_block_rows" | tee -a $OUT/summary.txt; }
 pass p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
 pass p2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVES
