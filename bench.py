@@ -55,8 +55,9 @@ WORKLOADS = {
     # from the empirical histograms of the real valid+test triples (the train split is not shipped with the reference)
     "fb237_block_traingraph": ("synth:fb237_valid_test:272115", 14541, 237, 500, 2, "block", 100, 272115),
     "toy_block": ("toy_train", 16, 9, 500, 2, "block", 100, 43),
-    # BASELINE.json configs[3]'s shape on one GPU: WN18 (V 40,943 / R 18), the 10,000 real valid+test triples as graph
-    "wn18_block": ("wn18_valid_test", 40943, 18, 500, 2, "block", 100, 10000),
+    # BASELINE.json configs[3]'s shape on one GPU at SURVEY 8d's size: WN18 (V 40,943 / R 18), a uniform 15,000-edge
+    # minibatch of the 141,442-edge training-graph shape (drawn from the real valid+test histograms)
+    "wn18_block": ("sample:wn18_valid_test:141442:15000", 40943, 18, 500, 2, "block", 100, 15000),
     # BASELINE.json configs[4]'s space on one GPU: FB15k (V 14,951 / R 1,345), 15,000 real valid triples as graph
     "fb15k_block": ("fb15k_minibatch", 14951, 1345, 500, 2, "block", 100, 15000),
     # BASELINE.json configs[2]: basis decomposition, B = 2 (and settings/gcn_basis.exp's own B = 5)
@@ -108,6 +109,11 @@ def load_graph(name):
         if name.startswith("synth:"):
             _, pool, n = name.split(":")
             return synthetic_from_histograms(z[pool], int(n), seed=0)
+        if name.startswith("sample:"):      # 'sample:<pool fixture>:<n_graph>:<n>': a uniform n-edge minibatch of that synthetic graph
+            _, pool, n_graph, n = name.split(":")
+            g = synthetic_from_histograms(z[pool], int(n_graph), seed=0)
+            pick = np.random.RandomState(3).choice(g.shape[0], size=int(n), replace=False)
+            return np.ascontiguousarray(g[np.sort(pick)])
         return np.ascontiguousarray(z[name].astype(np.int32))
 
 
@@ -548,7 +554,7 @@ def measure(workload, args, rk, steps, warmup, full):
     out = None
     if rank == 0:
         dataset = {"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(workload[:4], "FB15k-237")
-        if graph_name.startswith("synth:"):
+        if graph_name.startswith(("synth:", "sample:")):
             data = ("synthetic graph: %d unique triples, relation and endpoint-given-relation histograms of the real "
                     "FB15k-237 valid+test triples (SURVEY 8d graph B; the train split is not shipped), " % E_g)
         else:
@@ -886,6 +892,45 @@ def measure_evaluation(args, queries=2000):
     return out
 
 
+EVALUATION_ENCODES = {
+    # name: (training-graph shape, V, R, kind, nb)  -- the graph model.py:59-81 feeds when it scores: the FULL train graph
+    "fb237_basis_b2": ("synth:fb237_valid_test:272115", 14541, 237, "basis", 2),
+    "wn18_block": ("synth:wn18_valid_test:141442", 40943, 18, "block", 100),
+    "fb15k_block": ("synth:fb15k_minibatch:483142", 14951, 1345, "block", 100),
+}
+
+
+def measure_evaluation_encodes(args):
+    """The evaluation encode (test-mode forward pass over the whole training graph, code/model.py:59-81) of BASELINE
+    configs 3, 4 and 5 on one GPU: graph preparation + two layers, mean of 5 after a warm-up.  Element-wise parity of
+    exactly these graphs: tests/test_gpu_parity.py (test_training_graph_elementwise_parity_basis,
+    test_wn18_training_graph_elementwise_parity, test_fb15k_training_graph_evaluation_encode)."""
+    import numpy as np
+    from relationprediction_amd import _native
+    from relationprediction_amd.common.shared_functions import init_encoder_params
+    out = []
+    for name, (graph_name, V, R, kind, nb) in EVALUATION_ENCODES.items():
+        triples = load_graph(graph_name)
+        E, d, L = int(triples.shape[0]), 500, 2
+        with _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E) as eng:
+            eng.set_gemm_mode(args.gemm_mode)
+            eng.set_params(init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1)))
+            tri_dev = eng.to_device(triples)
+            eng.set_graph_device(tri_dev, E)
+            eng.forward(train=False)
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eng.set_graph_device(tri_dev, E)
+                eng.forward(train=False)
+            eng.sync()
+            ms = (time.perf_counter() - t0) * 1e3 / 5
+            tri_dev.free()
+        out.append({"workload": name, "graph_edges": E, "entities": V, "relations": R, "kind": kind,
+                    "encode_full_graph_ms": round(ms, 3), "edges_per_s": round(E / (ms * 1e-3), 1)})
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU; plain
     subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment -- the same
@@ -960,6 +1005,8 @@ def compact_line(out):
     ev = out.get("evaluation")
     line["evaluation"] = ({k: ev[k] for k in ("graph_edges", "queries", "encode_full_graph_ms", "rank_both_sides_ms",
                                                "ranked_triples_per_s")} if ev else None)
+    line["evaluation_encodes"] = [[e["workload"], e["graph_edges"], e["encode_full_graph_ms"]]
+                                  for e in out.get("evaluation_encodes", [])]
     tl = out.get("train_loop")
     line["train_loop"] = ({k: tl[k] for k in ("ms_per_iteration", "iterations_per_s", "device_step_ms", "device_idle_frac",
                                                "host_batch_build_ms", "ms_per_iteration_by_builder_threads",
@@ -1030,6 +1077,7 @@ def main():
         for w in TRAIN_STEP_WORKLOADS:
             train_steps.append(measure_train_step(w, args, args.extra_steps, min(args.warmup, 5)))
     evaluation = measure_evaluation(args) if widen else None
+    evaluation_encodes = measure_evaluation_encodes(args) if widen else []
     train_loop = (measure_train_loop(args, train_steps[0]["minibatch_step"]["ms_per_step"],
                                      iterations=max(20, 6 * args.extra_steps)) if widen else None)
     if rk.rank == 0 and rk.world == 1 and not args.no_live_traffic and not args.no_kernel_profile:
@@ -1038,6 +1086,7 @@ def main():
         out["workloads"] = extras
         out["train_steps"] = train_steps
         out["evaluation"] = evaluation
+        out["evaluation_encodes"] = evaluation_encodes
         out["train_loop"] = train_loop
         if rk.world == 1 and args.workload == "fb237_block":
             out["cpu_baseline_reference_code"] = reference_code_baseline()

@@ -30,6 +30,14 @@ rgcn_status rgcn_debug_gemm_time(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b
                                  int32_t K, int32_t split_k, int32_t iters, const float* a_host,
                                  const float* b_host, float* avg_ms);
 
+/* ---- placement self-check ---- */
+/* out_host[b] = the XCD (HW_REG_XCC_ID) workgroup b of a plain 1-D launch of n_blocks workgroups ran on.  The
+ * destination-major block layer (csrc/block_rows.hip) and the decoder's line kernel give column band x to the workgroups
+ * with blockIdx % 8 == x and count on them sharing one L2: a performance assumption HIP does not promise
+ * (MI355X_MICROARCH.md: "observed, for speed only: block b runs on XCD b % 8").  tests/test_gpu_parity.py::
+ * test_workgroups_of_a_band_share_an_xcd re-checks it on the box the suite runs on. */
+rgcn_status rgcn_debug_xcd_map(rgcn_ctx* ctx, int32_t n_blocks, int32_t* out_host);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

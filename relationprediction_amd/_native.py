@@ -126,6 +126,7 @@ _SIGS = {
 # librgcn_devtools.so only (include/rgcn_devtools.h)
 _DEVTOOLS_SIGS = {
     "rgcn_debug_gemm": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rgcn_debug_xcd_map": (C.c_int32, [_P, C.c_int32, _P]),
     "rgcn_debug_gemm_time": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, _P, _P, C.POINTER(C.c_float)]),
 }
@@ -679,6 +680,12 @@ class Engine:
             self._check(self.lib.rgcn_profile_get_compulsory(self.ctx, i, C.byref(cb)))
             out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
                         "alg_bytes": by.value, "alg_flops": fl.value, "compulsory_bytes": cb.value})
+        return out
+
+    def debug_xcd_map(self, n_blocks):
+        """XCD of every workgroup of a plain 1-D launch (devtools build)"""
+        out = np.zeros(int(n_blocks), dtype=np.int32)
+        self._check(self.lib.rgcn_debug_xcd_map(self.ctx, int(n_blocks), _ptr(out)))
         return out
 
     def debug_gemm_time(self, a, b, trans_a=False, trans_b=False, split_k=0, iters=20):

@@ -1687,6 +1687,27 @@ rgcn_status rgcn_profile_get_compulsory(rgcn_ctx* c, int32_t i, double* compulso
 }
 
 #ifdef RGCN_DEVTOOLS
+namespace {
+// the XCD every workgroup of a plain 1-D launch lands on (HW_REG_XCC_ID, bits 3:0)
+__global__ void k_xcd_of_block(int32_t* out) {
+  uint32_t id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(id & 0xf);
+}
+}  // namespace
+
+rgcn_status rgcn_debug_xcd_map(rgcn_ctx* c, int32_t n_blocks, int32_t* out_host) {
+  RGCN_NEED(c);
+  if (n_blocks <= 0 || !out_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  int32_t* dev = nullptr;
+  RGCN_TRY(dmalloc(c, &dev, (size_t)n_blocks));
+  hipLaunchKernelGGL(k_xcd_of_block, dim3((unsigned)n_blocks), dim3(256), 0, c->stream, dev);
+  rgcn_status s = hipGetLastError() == hipSuccess ? RGCN_OK : RGCN_ERR_HIP;
+  if (s == RGCN_OK) s = to_host(c, out_host, dev, sizeof(int32_t) * (size_t)n_blocks);
+  (void)hipFree(dev);
+  return s;
+}
+
 rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
                             int32_t split_k, const float* a_host, const float* b_host, float* c_host) {
   RGCN_NEED(c);

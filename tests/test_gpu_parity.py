@@ -52,6 +52,15 @@ def compare(acts, grads, oacts, ograds, tag=""):
         assert_close(g, ograds[name], rel=2e-4, name="%s grad %s" % (tag, name))
 
 
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_graphs", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
 def gate_aware_gradient_check(c, acts, grads, norm, direct):
     """Second line of the gradient check (helpers.gate_consistent_oracle_grads): only taken when a handful
     of relu gates sit within rounding of zero; then the engine's backward must match the oracle's
@@ -474,7 +483,7 @@ def test_full_graph_inference_shape(native):
 def _shape_case_full_parity(native, V, R, d, L, nb, graph, seed, tag):
     """Forward (train mode, injected masks) and EVERY gradient of a block-kind case against the oracle; when an
     isolated relu gate within rounding of zero trips the direct gradient comparison, the gate-consistent check."""
-    triples = helpers.load_graph(graph)
+    triples = _bench_module().load_graph(graph) if ":" in graph else helpers.load_graph(graph)
     rng = np.random.RandomState(seed)
     params = oracle.init_params(V, R, d, L, "block", nb, rng=rng)
     params["b_emb"] = (rng.randn(d) * 0.01).astype(np.float32)
@@ -497,6 +506,12 @@ def test_wn18_shape_full_parity(native):
     of the edges), the 10,000 real valid+test triples as graph, d = 500, block kind, train mode with injected
     masks: every activation and every gradient (W_emb, b_emb, both layers' W_f / W_b / W_self)."""
     _shape_case_full_parity(native, 40943, 18, 500, 2, 100, "wn18_valid_test", 11, "wn18")
+
+
+def test_wn18_minibatch_full_parity(native):
+    """BASELINE config 4 at SURVEY 8d's minibatch size -- bench.py's `wn18_block` workload itself: a uniform 15,000-edge
+    minibatch of the 141,442-edge WN18 training-graph shape: every activation and every gradient against the oracle."""
+    _shape_case_full_parity(native, 40943, 18, 500, 2, 100, "sample:wn18_valid_test:141442:15000", 13, "wn18-15k")
 
 
 def test_fb15k_shape_full_parity(native):
@@ -722,6 +737,21 @@ def test_single_pass_layer_equals_the_two_kernel_form(native, V, R, d, nb, E, hu
     assert np.isfinite(fa[2]).all() and (E == 0 or np.abs(fg["W_f1"]).max() > 0)
 
 
+def test_workgroups_of_a_band_share_an_xcd(native):
+    """k_block_rows (and the decoder's line kernel) hand column band x to the workgroups with blockIdx % 8 == x and count
+    on those sharing one XCD's L2 (0.6 MB of weights + 3.6 MB of operand band per XCD).  HIP does not promise the
+    round-robin placement -- results never depend on it, speed does -- so the suite re-checks it where it runs: in a
+    plain launch every residue class of blockIdx % 8 sits on ONE XCD and the eight classes on eight different ones."""
+    with native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True) as eng:
+        for n in (8, 64, 2048, 3697):
+            x = eng.debug_xcd_map(n)
+            assert x.min() >= 0 and x.max() <= 7
+            for r in range(min(8, n)):
+                assert len(set(x[r::8].tolist())) == 1, (n, r, sorted(set(x[r::8].tolist())))
+            if n >= 8:
+                assert len(set(x[:8].tolist())) == 8, x[:8]
+
+
 def test_bias_gradient_from_the_row_kernel_is_the_same_in_every_engine(native):
     """db_emb comes from column partials the bottom layer's row-gradient kernel leaves behind (block_rows.hip): every
     workgroup sums the rows IT writes, so which workgroup takes which row must not depend on anything that differs from
@@ -844,15 +874,6 @@ def test_training_graph_scale_properties(native):
         lin = 0.7 * grads[0][k] - 1.3 * grads[1][k]
         sc = max(float(np.abs(grads[0][k]).max()), float(np.abs(grads[1][k]).max()), 1e-30)
         assert float(np.abs(grads[2][k] - lin).max()) <= 2e-5 * sc, (k, float(np.abs(grads[2][k] - lin).max()), sc)
-
-
-def _bench_module():
-    import importlib.util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("bench_for_graphs", os.path.join(root, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    return bench
 
 
 def _elementwise_parity_at_scale(native, triples, V, R, kind, nb, seed, want_giant=False, gradients=True,
