@@ -30,6 +30,13 @@ rgcn_status rgcn_debug_gemm_time(rgcn_ctx* ctx, int32_t trans_a, int32_t trans_b
                                  int32_t K, int32_t split_k, int32_t iters, const float* a_host,
                                  const float* b_host, float* avg_ms);
 
+/* C[M,N] = A . op(B) with B handed to the kernel PRE-SPLIT into bf16 planes in MFMA fragment order -- the way the encoder
+ * passes its weights (W_self, the basis tensors) since round 5, csrc/gemm_bf16x3.hip B_PRE.  A is [M,K]; trans_b == 0: B
+ * is [K,N], else [N,K].  Bitwise the result of rgcn_debug_gemm on the same operands (split arithmetic, modes 6 / 9;
+ * mode 0 ignores the table).  iters > 0: also the mean time of one product over that many launches. */
+rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* ctx, int32_t trans_b, int32_t M, int32_t N, int32_t K, int32_t iters,
+                                     const float* a_host, const float* b_host, float* c_host, float* avg_ms);
+
 /* ---- placement self-check ---- */
 /* out_host[b] = the XCD (HW_REG_XCC_ID) workgroup b of a plain 1-D launch of n_blocks workgroups ran on.  The
  * destination-major block layer (csrc/block_rows.hip) and the decoder's line kernel give column band x to the workgroups

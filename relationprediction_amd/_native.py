@@ -127,6 +127,8 @@ _SIGS = {
 _DEVTOOLS_SIGS = {
     "rgcn_debug_gemm": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rgcn_debug_xcd_map": (C.c_int32, [_P, C.c_int32, _P]),
+    "rgcn_debug_gemm_presplit": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
+                                             C.POINTER(C.c_float)]),
     "rgcn_debug_gemm_time": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, _P, _P, C.POINTER(C.c_float)]),
 }
@@ -681,6 +683,18 @@ class Engine:
             out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
                         "alg_bytes": by.value, "alg_flops": fl.value, "compulsory_bytes": cb.value})
         return out
+
+    def debug_gemm_presplit(self, a, b, trans_b=False, iters=0):
+        """A . op(B) with B pre-split into MFMA fragments (devtools build); returns C, or (C, ms per product) if iters"""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        M, K = a.shape
+        N = b.shape[0] if trans_b else b.shape[1]
+        out = np.empty((M, N), dtype=np.float32)
+        ms = C.c_float()
+        self._check(self.lib.rgcn_debug_gemm_presplit(self.ctx, int(trans_b), M, N, K, int(iters), _ptr(a), _ptr(b),
+                                                      _ptr(out), C.byref(ms)))
+        return (out, float(ms.value)) if iters else out
 
     def debug_xcd_map(self, n_blocks):
         """XCD of every workgroup of a plain 1-D launch (devtools build)"""

@@ -67,6 +67,8 @@ struct XArgs {
   int swizzle;
   int vecC;
   GemmBatch batch;    // groups (blockIdx.y) and their device-side extents
+  const u32x4* bfrag; // B_PRE instantiations: B pre-split into MFMA fragments (k_presplit_b), [ktiles][nt32][3][2][32]
+  int nt32;           // 32-column tiles of the fragment table (4 x tiles_n)
 };
 
 constexpr int BM = 128, BN = 128, BK = 16, NTH = 256;
@@ -230,10 +232,17 @@ __device__ __forceinline__ bf16x8 load_frag(const uint32_t* __restrict__ plane, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TERMS>
+// B_PRE: the B operand is a WEIGHT that k_presplit_b has already split into its three bf16 planes, stored in the order
+// the MFMA wants its fragments (GemmArgs::bfrag).  Each wave then fetches the 2 x 3 fragments of a k-tile straight from
+// L2 into registers with six coalesced 16-byte loads, one k-tile ahead: no global -> register -> split -> LDS -> register
+// round trip for B, i.e. half the LDS reads and writes of a step, half its split VALU work and half the LDS footprint;
+// A (the activations) keeps the staged path.  Same products in the same order: bitwise the plain kernel's result.
+// (Measured, profiles/r05_gemm_presplit.md: 5-12 % on the NN form, 0-6 % on NT; letting the two waves that own the same 64
+// columns fetch half of the fragments each and swap them through LDS -- half the L1 requests -- changed nothing.)
+template <bool A_KC, bool B_KC, bool VEC, int TERMS, bool B_PRE = false>
 __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   constexpr int PA = A_KC ? KC_PLANE : RC_PLANE, PB = B_KC ? KC_PLANE : RC_PLANE;
-  constexpr int TA = 3 * PA, TB = 3 * PB;
+  constexpr int TA = 3 * PA, TB = B_PRE ? 0 : 3 * PB;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
   int wg = blockIdx.x;
@@ -298,8 +307,10 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
   auto gload = [&](int k0, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
     if constexpr (A_KC) load_kc<VEC>(gA, g.zeros, g.lda, Mlim, m0, k0, ke, xa);
     else load_rc<VEC>(gA, g.zeros, g.lda, Mlim, m0, k0, ke, xa);
-    if constexpr (B_KC) load_kc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
-    else load_rc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
+    if constexpr (!B_PRE) {
+      if constexpr (B_KC) load_kc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
+      else load_rc<VEC>(gB, g.zeros, g.ldb, g.N, n0, k0, ke, xb);
+    }
   };
   // Full tiles of a 16-byte-loadable operand are fetched through per-thread walking pointers (one
   // 64-bit add per load and step instead of the whole address + validity computation); a thread whose
@@ -319,7 +330,9 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
         wa[p] = row < Mlim ? gA + (size_t)k * g.lda + row : g.zeros;
         ia[p] = row < Mlim ? BK * g.lda : 0;
       }
-      if constexpr (B_KC) {
+      if constexpr (B_PRE) {
+        wb[p] = g.zeros;
+      } else if constexpr (B_KC) {
         const int f = threadIdx.x + NTH * p, row = n0 + (f >> 2);
         wb[p] = row < g.N ? gB + (size_t)row * g.ldb + ks + (f & 3) * 4 : g.zeros;
         ib[p] = row < g.N ? BK : 0;
@@ -336,15 +349,30 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       xa[p] = *reinterpret_cast<const f32x4*>(wa[p]);
-      xb[p] = *reinterpret_cast<const f32x4*>(wb[p]);
       wa[p] += ia[p];
-      wb[p] += ib[p];
+      if constexpr (!B_PRE) {
+        xb[p] = *reinterpret_cast<const f32x4*>(wb[p]);
+        wb[p] += ib[p];
+      }
     }
   };
   auto sstore = [&](uint32_t* buf, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
     SplitRegs st;
     split_chunks<A_KC, PA, 0, 12>(xa, st, buf);
-    split_chunks<B_KC, PB, 0, 12>(xb, st, buf + TA);
+    if constexpr (!B_PRE) split_chunks<B_KC, PB, 0, 12>(xb, st, buf + TA);
+  };
+  // B_PRE: this lane's fragments of k-tile kt_abs (two 32-column tiles x three planes), one k-tile ahead of their use
+  const int nkt_all = (g.K + BK - 1) / BK;
+  const u32x4* const bq = B_PRE ? g.bfrag + (size_t)grp * g.batch.strideBfrag +
+                                      ((size_t)((n0 + wn) >> 5) * 6 + h) * 32 + li
+                                : nullptr;
+  bf16x8 fbp[2][2][3];
+  auto bfetch = [&](int kt_abs, bf16x8 (&f)[2][3]) {
+    const u32x4* q = bq + (size_t)min(kt_abs, nkt_all - 1) * g.nt32 * 192;      // (a tile past the end meets a zero A tile)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f[j][pl] = __builtin_bit_cast(bf16x8, q[(j * 3 + pl) * 64]);
   };
   // Accumulator sign groups.  v_mfma_f32_32x32x16_bf16 adds products that are small beside the accumulator with a
   // bias toward -inf: about -0.004 ulp of the accumulator per MFMA whose products are 2^-9 .. 2^-24 of it, none for
@@ -378,6 +406,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     if (kt == flip[0] || kt == flip[1] || kt == flip[2]) negate_acc();      // tile kt opens a group of the other sign
     const uint32_t negmask = (sign_group(kt + 1) & 1) ? 0x80000000u : 0u;   // sign of the tile this step stages
     if constexpr (WALK) gwalk(ra[P], rb[P]); else gload(ks + (kt + 2) * BK, ra[P], rb[P]);
+    if constexpr (B_PRE) bfetch(kt + 1, fbp[1 - P]);
     const uint32_t* a_lds = lds + P * (TA + TB);
     const uint32_t* b_lds = a_lds + TA;
     uint32_t* nxt = lds + (1 - P) * (TA + TB);
@@ -389,7 +418,10 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb[j][pl] = load_frag<B_KC>(b_lds + pl * PB, wn + 32 * j + li, h);
+      for (int pl = 0; pl < 3; ++pl) {
+        if constexpr (B_PRE) fb[j][pl] = fbp[P][j][pl];
+        else fb[j][pl] = load_frag<B_KC>(b_lds + pl * PB, wn + 32 * j + li, h);
+      }
     __builtin_amdgcn_sched_barrier(0);
     // partial products from the smallest to the largest; plane 0 = hi, 1 = mid, 2 = lo.  Behind MFMA m
     // goes conversion chunk m of the NEXT tile (24 chunks; order pinned by the scheduling fences).
@@ -397,15 +429,19 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     constexpr int pa_[NP] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
     constexpr int pb_[NP] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
     constexpr int NM = 4 * TERMS;                       // MFMAs per step
-    constexpr int PER = (24 + NM - 1) / NM;             // chunks behind each MFMA
+    constexpr int NCH = B_PRE ? 12 : 24;                // conversion chunks of a step (A alone when B comes pre-split)
+    constexpr int PER = (NCH + NM - 1) / NM;            // chunks behind each MFMA
     SplitRegs st;
     auto weave = [&](auto mi) {
       constexpr int m = decltype(mi)::value;
       constexpr int t = NP - TERMS + m / 4, i = (m / 2) % 2, j = m % 2;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_[t]], fb[j][pb_[t]], acc[i][j], 0, 0, 0);
-      constexpr int c0 = m * PER < 24 ? m * PER : 24, c1 = (m + 1) * PER < 24 ? (m + 1) * PER : 24;
+      // (B_PRE: the twelve chunks of A behind every other MFMA, as far apart as before)
+      constexpr int c0 = B_PRE ? (m % 2 == 0 ? m / 2 : 12) : (m * PER < 24 ? m * PER : 24);
+      constexpr int c1 = B_PRE ? (m % 2 == 0 ? (m / 2 + 1 < 12 ? m / 2 + 1 : 12) : 12) : ((m + 1) * PER < 24 ? (m + 1) * PER : 24);
       split_chunks<A_KC, PA, (c0 < 12 ? c0 : 12), (c1 < 12 ? c1 : 12)>(ra[1 - P], st, nxt, negmask);
-      split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
+      if constexpr (!B_PRE)
+        split_chunks<B_KC, PB, (c0 > 12 ? c0 - 12 : 0), (c1 > 12 ? c1 - 12 : 0)>(rb[1 - P], st, nxt + TA);
       __builtin_amdgcn_sched_barrier(0);
     };
     static_for<0, NM>(weave);
@@ -414,6 +450,7 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
 
   if (nkt > 0) {
     gload(ks, ra[0], rb[0]);
+    if constexpr (B_PRE) bfetch(0, fbp[0]);
     sstore(lds, ra[0], rb[0]);
     gload(ks + BK, ra[1], rb[1]);
   }
@@ -483,16 +520,16 @@ __global__ void __launch_bounds__(NTH, 2) k_gemm_bf16x3(XArgs g) {
     }
 }
 
-constexpr size_t lds_bytes(bool a_kc, bool b_kc) {
-  const size_t tiles = 2 * 3 * ((a_kc ? KC_PLANE : RC_PLANE) + (b_kc ? KC_PLANE : RC_PLANE)) * 4;
+constexpr size_t lds_bytes(bool a_kc, bool b_kc, bool b_pre = false) {
+  const size_t tiles = 2 * 3 * ((a_kc ? KC_PLANE : RC_PLANE) + (b_pre ? 0 : (b_kc ? KC_PLANE : RC_PLANE))) * 4;
   const size_t epi = 64 * EPI_LD * 4;       // 64 staged rows of the product
   return tiles > epi ? tiles : epi;
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TERMS>
+template <bool A_KC, bool B_KC, bool VEC, int TERMS, bool B_PRE = false>
 hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
-  constexpr size_t bytes = lds_bytes(A_KC, B_KC);
-  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS>;
+  constexpr size_t bytes = lds_bytes(A_KC, B_KC, B_PRE);
+  auto kern = k_gemm_bf16x3<A_KC, B_KC, VEC, TERMS, B_PRE>;
   static bool configured = false;     // per instantiation; contexts are single-threaded per process
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -507,12 +544,73 @@ hipError_t launch_one(rgcn_ctx* c, const XArgs& g) {
 
 template <bool VEC, int TERMS>
 hipError_t launch_form(rgcn_ctx* c, bool a_kc, bool b_kc, const XArgs& g) {
+  if constexpr (VEC) {      // pre-split B: k-contiguous A with 16-byte rows, no split over K (the caller checks)
+    if (g.bfrag != nullptr && a_kc) return launch_one<true, true, true, TERMS, true>(c, g);
+  }
   if (a_kc && !b_kc) return launch_one<true, false, VEC, TERMS>(c, g);
   if (a_kc && b_kc) return launch_one<true, true, VEC, TERMS>(c, g);
   return launch_one<false, false, VEC, TERMS>(c, g);
 }
 
+// B (k, n) of a contraction -- stored [n][k] (B_KC) or [k][n] -- split ONCE into the three bf16 planes, laid out so that
+// lane (li, h) of the wave that owns 32-column tile nt finds the eight k = 16 kt + 8 h .. + 7 of column 32 nt + li of
+// plane p in ONE aligned 16-byte word: F[kt][nt][p][h][li].  Zero beyond K and N.  The arithmetic is split_level's, the
+// word order load_frag's: the B_PRE kernel feeds the MFMAs bit for bit what the staged path does.
+template <bool B_KC>
+__global__ void __launch_bounds__(256) k_presplit_b(const float* __restrict__ B, int ldb, int K, int N, int ktiles, int nt32,
+                                                    u32x4* __restrict__ F, size_t strideB, size_t strideF) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ktiles * nt32 * 64) return;
+  B += (size_t)blockIdx.y * strideB;
+  F += (size_t)blockIdx.y * strideF;
+  const int li = i & 31, h = (i >> 5) & 1, nt = (i >> 6) % nt32, kt = (i >> 6) / nt32;
+  const int n = 32 * nt + li, k0 = 16 * kt + 8 * h;
+  f32x4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};      // k0 .. k0 + 3, k0 + 4 .. k0 + 7
+  if (n < N) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + q;
+      const float x = k < K ? (B_KC ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.0f;
+      if (q < 4) lo4[q] = x; else hi4[q - 4] = x;
+    }
+  }
+  u32x4* dst = F + ((size_t)(kt * nt32 + nt) * 6 + h) * 32 + li;
+#pragma unroll
+  for (int level = 0; level < 3; ++level) {
+    u32x4 w;
+    if (level < 2) {
+      w[0] = split_level<0, 1>(lo4, lo4); w[1] = split_level<2, 3>(lo4, lo4);
+      w[2] = split_level<0, 1>(hi4, hi4); w[3] = split_level<2, 3>(hi4, hi4);
+    } else {
+      w[0] = split_last(lo4[0], lo4[1]); w[1] = split_last(lo4[2], lo4[3]);
+      w[2] = split_last(hi4[0], hi4[1]); w[3] = split_last(hi4[2], hi4[3]);
+    }
+    dst[level * 64] = w;
+  }
+}
+
 }  // namespace
+
+size_t gemm_bfrag_words(int K, int N) {      // 16-byte words of one operand's fragment table
+  return (size_t)((K + BK - 1) / BK) * (4 * ((N + BN - 1) / BN)) * 192;
+}
+
+// F = the fragment table of B (k, n) for the B_PRE kernel; `groups` operands strideB floats / strideF words apart
+rgcn_status gemm_presplit_b(rgcn_ctx* c, const float* B, bool b_kc, int K, int N, int ldb, void* F, int groups,
+                            size_t strideB, size_t strideF) {
+  const int ktiles = (K + BK - 1) / BK, nt32 = 4 * ((N + BN - 1) / BN);
+  const int threads = ktiles * nt32 * 64;
+  ProfScope ps(c, "gemm_presplit_b", groups * (4.0 * K * N + 16.0 * 3 * threads), 0);
+  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)groups), block(256);
+  if (b_kc)
+    hipLaunchKernelGGL((k_presplit_b<true>), grid, block, 0, c->stream, B, ldb, K, N, ktiles, nt32,
+                       reinterpret_cast<u32x4*>(F), strideB, strideF);
+  else
+    hipLaunchKernelGGL((k_presplit_b<false>), grid, block, 0, c->stream, B, ldb, K, N, ktiles, nt32,
+                       reinterpret_cast<u32x4*>(F), strideB, strideF);
+  RGCN_HIP(c, hipGetLastError());
+  return RGCN_OK;
+}
 
 // Called by gemm_f32() when the context's gemm mode asks for the split evaluation; same contract.
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
@@ -520,11 +618,13 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
                               int k_per_split, int splits, int swizzle, int vecC, const GemmBatch* batch) {
   XArgs g;
   if (batch) g.batch = *batch;
+  g.bfrag = (batch && batch->bfrag && splits == 1 && a_kc && vec) ? reinterpret_cast<const u32x4*>(batch->bfrag) : nullptr;
   g.A = A; g.B = B; g.C = C; g.zeros = c->zeros;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.k_per_split = k_per_split; g.splits = splits; g.swizzle = swizzle; g.vecC = vecC;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
+  g.nt32 = 4 * g.tiles_n;
   if (terms == 9) return vec ? launch_form<true, 9>(c, a_kc, b_kc, g) : launch_form<false, 9>(c, a_kc, b_kc, g);
   if (terms == 3) return vec ? launch_form<true, 3>(c, a_kc, b_kc, g) : launch_form<false, 3>(c, a_kc, b_kc, g);
   return vec ? launch_form<true, 6>(c, a_kc, b_kc, g) : launch_form<false, 6>(c, a_kc, b_kc, g);

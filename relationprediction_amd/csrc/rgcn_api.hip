@@ -275,6 +275,7 @@ static void free_all(rgcn_ctx* c) {
       if (c->kind == RGCN_KIND_BASIS) lb.grel = nullptr;
     }
     F(lb.wrel); F(lb.grel); F(lb.coef); F(lb.gcoef); F(lb.wself); F(lb.gwself); F(lb.bias); F(lb.gbias); F(lb.wtile);
+    F(lb.wself_nn); F(lb.wself_nt); F(lb.wrel_nn); F(lb.wrel_nt);
   }
   for (float* h : c->H) F(h);
   F(c->self_buf); F(c->exch); F(c->dbuf[0]); F(c->dbuf[1]); F(c->dsbuf[0]); F(c->dsbuf[1]);
@@ -420,6 +421,16 @@ static rgcn_status create_impl(rgcn_ctx* c) {
       add_param(c, "C_b" + sl, {(int64_t)R, c->B}, lb.coef + R * c->B, lb.gcoef + R * c->B, LAYOUT_PLAIN);
     }
     RGCN_TRY(dmalloc(c, &lb.wself, d * d));
+    {      // fragment tables (allocated here: a capture may be the first call that needs them)
+      const size_t ws = 16 * gemm_bfrag_words((int)d, (int)d);
+      RGCN_HIP(c, hipMalloc(&lb.wself_nn, ws));
+      RGCN_HIP(c, hipMalloc(&lb.wself_nt, ws));
+      if (c->kind == RGCN_KIND_BASIS) {
+        const int Bd = c->B * (int)d;
+        RGCN_HIP(c, hipMalloc(&lb.wrel_nn, 2 * 16 * gemm_bfrag_words(Bd, (int)d)));
+        RGCN_HIP(c, hipMalloc(&lb.wrel_nt, 2 * 16 * gemm_bfrag_words((int)d, Bd)));
+      }
+    }
     if (repl) lb.gwself = repl;
     else RGCN_TRY(dmalloc(c, &lb.gwself, d * d));
     RGCN_TRY(dmalloc(c, &lb.bias, d));
@@ -542,6 +553,28 @@ static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
 // cover) the two-kernel form: relation-major message kernel + k_combine.
 static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 1 && block_rows_available(c); }
 
+// Fragment table of a weight that is the B operand of a contraction, rebuilt when the weights changed (set_param, Adam)
+// -- and inside every captured step, whose replays follow weights the host does not see.  Returns nullptr when the
+// dense contractions run on the fp32 MFMA (no split, nothing to pre-split).
+static rgcn_status weight_fragments(rgcn_ctx* c, void* table, uint64_t* version, const float* W, bool b_kc, int K, int N,
+                                    int ldb, int groups, size_t strideW, const void** out) {
+  *out = nullptr;
+  if (c->gemm_mode == 0 || table == nullptr) return RGCN_OK;
+  if (c->capturing || *version != c->weights_version) {
+    RGCN_TRY(gemm_presplit_b(c, W, b_kc, K, N, ldb, table, groups, strideW, gemm_bfrag_words(K, N)));
+    *version = c->capturing ? ~0ull : c->weights_version;
+  }
+  *out = table;
+  return RGCN_OK;
+}
+// the self-loop products: one group, W_self as the pre-split B operand (forward: [k][n]; dH: used transposed, [n][k])
+static rgcn_status self_loop_batch(rgcn_ctx* c, int l, bool transposed, GemmBatch* b) {
+  LayerBufs& lb = c->layers[l];
+  *b = GemmBatch();
+  return weight_fragments(c, transposed ? lb.wself_nt : lb.wself_nn, transposed ? &lb.wself_nt_version : &lb.wself_nn_version,
+                          lb.wself, transposed, c->d, c->d, c->d, 1, 0, &b->bfrag);
+}
+
 // Basis kind: the two direction groups of a batched GEMM over the (row, direction) units of the current graph; the
 // group's extent (rows of A / C, or the depth of dW') is the direction's unit count, read on the device.
 static GemmBatch basis_batch(const rgcn_ctx* c, size_t strideA, size_t strideB, size_t strideC, bool limit_on_k) {
@@ -562,6 +595,8 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
   const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
   float* dst = c->world > 1 ? c->exch : c->H[l];
   const double Mmsg = 2.0 * c->g.E / c->world;
+  GemmBatch sb;
+  RGCN_TRY(self_loop_batch(c, l, false, &sb));
   if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
     // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
     // the incidence CSR (no message buffer)
@@ -569,7 +604,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     // the PARTIAL pre-activations -- the self-loop term inside the shard only, no relu -- for the reduce-scatter that
     // follows)
     RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d, c->layers[l].wself, d,
-                      c->self_buf + (size_t)lo * d, d, 1));
+                      c->self_buf + (size_t)lo * d, d, 1, &sb));
     RGCN_TRY(wait_gather(c));
     CombineArgs a;
     a.add = nullptr; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
@@ -586,7 +621,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     {   // self-loop: S = H . W_self  (rows of this rank's shard)
       StreamScope side(c, 0);
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1, &sb));
     }
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
@@ -609,11 +644,14 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     {
       StreamScope side(c, 1);
       RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1));
+                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1, &sb));
     }
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
-    const GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
+    GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
+    RGCN_TRY(weight_fragments(c, c->layers[l].wrel_nn, &c->layers[l].wrel_nn_version, c->layers[l].wrel, false, Bd, d, d, 2,
+                              (size_t)Bd * d, &gb.bfrag));
+    gb.strideBfrag = gemm_bfrag_words(Bd, d);
     RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
                       c->aggbuf, d, 1, &gb, basis_unit_share(c)));
     RGCN_TRY(stream_join(c, 1));
@@ -694,9 +732,11 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     return gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
                     lb.gwself, d, auto_split_k(d, d, rows, narrow_dw));
   };
+  GemmBatch sbt;
+  RGCN_TRY(self_loop_batch(c, l, true, &sbt));
   auto self_dh = [&]() {      // G = dS . W_self^T
     return gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                    c->self_buf + (size_t)lo * d, d, 1);
+                    c->self_buf + (size_t)lo * d, d, 1, &sbt);
   };
   if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
     // Row gradients: the single-pass kernel behind G = dS . W_self^T.  Relation-weight gradients (dW_r = sum n g (x) x,
@@ -790,7 +830,9 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     }
     RGCN_TRY(self_dh());
     // dZc_dir = Dc_dir . W'_dir^T   ([units, d] x [d, B.d], two groups)
-    const GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
+    GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
+    RGCN_TRY(weight_fragments(c, lb.wrel_nt, &lb.wrel_nt_version, lb.wrel, true, d, Bd, d, 2, (size_t)Bd * d, &gm.bfrag));
+    gm.strideBfrag = gemm_bfrag_words(d, Bd);
     RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, &gm,
                       basis_unit_share(c)));
     RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
@@ -1731,6 +1773,43 @@ rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int3
   if (A) (void)hipFree(A);
   if (B) (void)hipFree(B);
   if (C) (void)hipFree(C);
+  return s;
+}
+
+rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* c, int32_t tb, int32_t M, int32_t N, int32_t K, int32_t iters,
+                                     const float* a_host, const float* b_host, float* c_host, float* avg_ms) {
+  RGCN_NEED(c);
+  if (M <= 0 || N <= 0 || K <= 0 || !a_host || !b_host || !c_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
+  float *A = nullptr, *B = nullptr, *C = nullptr;
+  void* F = nullptr;
+  rgcn_status s = RGCN_OK;
+  do {
+    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
+    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
+    if (hipMalloc(&F, 16 * gemm_bfrag_words(K, N)) != hipSuccess) { s = RGCN_ERR_NOMEM; break; }
+    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
+    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
+    if ((s = gemm_presplit_b(c, B, tb != 0, K, N, tb ? K : N, F)) != RGCN_OK) break;
+    GemmBatch gb;
+    gb.bfrag = F;
+    s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
+    if (s != RGCN_OK) break;
+    if ((s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N)) != RGCN_OK) break;
+    if (iters > 0 && avg_ms) {
+      if ((s = rgcn_timer_start(c)) != RGCN_OK) break;
+      for (int it = 0; it < iters && s == RGCN_OK; ++it)
+        s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
+      if (s != RGCN_OK) break;
+      float ms = 0.f;
+      if ((s = rgcn_timer_stop(c, &ms)) != RGCN_OK) break;
+      *avg_ms = ms / iters;
+    }
+  } while (0);
+  if (A) (void)hipFree(A);
+  if (B) (void)hipFree(B);
+  if (C) (void)hipFree(C);
+  if (F) (void)hipFree(F);
   return s;
 }
 

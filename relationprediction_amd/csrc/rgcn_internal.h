@@ -162,6 +162,11 @@ struct LayerBufs {
   float* gwself = nullptr;
   float* bias = nullptr;    // [d], unused by the math
   float* gbias = nullptr;
+  // MFMA-fragment tables of the weights that are the B operand of a contraction (gemm_presplit_b: the three bf16 planes of
+  // the exact split, in fragment order), rebuilt when the weights change: W_self for H.W_self (nn) and dS.W_self^T (nt);
+  // basis kind: W'_dir for Zc.W' (nn) and Dc.W'^T (nt), two groups each.  Split arithmetic only (rgcn_set_gemm_mode 6 / 9).
+  void *wself_nn = nullptr, *wself_nt = nullptr, *wrel_nn = nullptr, *wrel_nt = nullptr;
+  uint64_t wself_nn_version = ~0ull, wself_nt_version = ~0ull, wrel_nn_version = ~0ull, wrel_nt_version = ~0ull;
   // BLOCK, destination-major banded layer kernel (block_rows.hip): band-tiled copy of wrel,
   // [2R][8 bands][ceil(sd*sd/4)][GW lanes][4], allocated at first use
   float* wtile = nullptr;
@@ -479,7 +484,15 @@ struct GemmBatch {
   const int32_t* limit = nullptr;                 // device, limit[g * limit_stride]: extent of group g (<= M resp. K)
   int limit_stride = 1;
   int limit_on_k = 0;                             // 0: rows of A / C; 1: depth K
+  // optional: B already split into bf16 planes in MFMA fragment order (gemm_presplit_b; a weight, split once per weight
+  // update instead of once per tile and step).  Used by the split-arithmetic kernel when A is k-contiguous and there is no
+  // split over K; ignored otherwise (B itself must still be passed).  strideBfrag: 16-byte words between groups.
+  const void* bfrag = nullptr;
+  size_t strideBfrag = 0;
 };
+size_t gemm_bfrag_words(int K, int N);
+rgcn_status gemm_presplit_b(rgcn_ctx* c, const float* B, bool b_kc, int K, int N, int ldb, void* F, int groups = 1,
+                            size_t strideB = 0, size_t strideF = 0);
 
 // C[M,N] (ldc) = A(m,k) . B(k,n).  a_kc: A stored [m][k] (k contiguous, lda) else [k][m];
 // b_kc: B stored [n][k] (k contiguous, ldb) else [k][n].  split_k > 1 writes partial slabs to

@@ -110,6 +110,28 @@ def test_gemm_forms(native, M, N, K, form, mode):
     assert_close(got, ref, rel=1e-5, spike=1e-5, name=form)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (129, 132, 36), (257, 500, 500), (1000, 500, 500), (300, 500, 5000),
+                                   (300, 5000, 500), (64, 64, 4), (14541, 500, 500)])
+@pytest.mark.parametrize("trans_b", [False, True])
+@pytest.mark.parametrize("mode", [6, 9])
+def test_gemm_with_presplit_weights_is_bitwise_the_staged_kernel(native, M, N, K, trans_b, mode):
+    """The weights (W_self, the basis tensors) reach the split-arithmetic GEMM pre-split into bf16 planes in MFMA fragment
+    order (gemm_bf16x3.hip B_PRE: straight from L2 into registers, no LDS staging for B): the same products in the same
+    order as the staged kernel -- bitwise equal, ragged edges in M, N and K included -- and right against float64."""
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rng.randn(M, K).astype(np.float32)
+    B = (rng.randn(K, N) * np.exp(rng.uniform(-6, 6, (K, N)))).astype(np.float32)
+    Bop = np.ascontiguousarray(B.T) if trans_b else B
+    with native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True) as eng:
+        eng.set_gemm_mode(mode)
+        staged = eng.debug_gemm(A, Bop, trans_b=trans_b, split_k=1)
+        pre = eng.debug_gemm_presplit(A, Bop, trans_b=trans_b)
+    np.testing.assert_array_equal(pre, staged)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert float((np.abs(pre - ref) / mag).max()) < 2e-6
+
+
 def test_gemm_modes_are_fp32_accurate(native):
     """The split evaluation must be as accurate as the fp32 MFMA on the encoder's own shapes: error against
     float64, normalised by sum |a||b| (the scale fp32 rounding errors live on), within 1.5x of mode 0's, and
