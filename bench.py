@@ -160,7 +160,7 @@ KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "
                  "gemm_self_dw": "k_gemm_bf16x3<false, false", "block_msg_fwd": "k_block_msg_fwd",
                  "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine",
                  "input_fwd": "k_input_fwd", "top_grad_dropout": "k_scale_dropout", "block_dw_reduce": "k_block_dw_reduce",
-                 "splitk_reduce": "k_splitk_reduce", "bias_grad_colsum": "k_colsum_part", "prep_sort": "k_sort_scatter",
+                 "splitk_reduce": "k_splitk_reduce", "prep_sort": "k_sort_scatter",
                  "prep_keys": "k_keys", "prep_ptrs": "k_ptrs", "prep_build_msgs": "k_build_msgs",
                  "gemm_basis_fwd": "k_gemm_bf16x3<true, false", "gemm_basis_dz": "k_gemm_bf16x3<true, true",
                  "gemm_basis_dw": "k_gemm_bf16x3<false, false", "basis_agg": "k_basis_agg",
@@ -168,7 +168,9 @@ KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "
                  # (prefix, substring): template arguments in the middle of the name tell the instantiations apart
                  "block_rows_fwd": ("k_block_rows<", ", false,"), "block_rows_bwd": ("k_block_rows<", ", true,"),
                  "block_dw_msgs": ("k_block_msg_bwd<", ", false>"), "prep_row_order": "k_sort_hist",
-                 "block_wtile_build": "k_wtile_build"}
+                 "block_wtile_build": "k_wtile_build", "basis_aggregate": "k_basis_agg",
+                 "basis_gather_units": "k_gather_units", "gemm_presplit_b": "k_presplit_b", "prep_scan": "k_exscan",
+                 "bias_grad_colsum": "k_colsum_final", "basis_dcoef_reduce": "k_basis_dcoef_reduce"}
 
 
 def kernel_traffic(traffic, tag, args):

@@ -112,17 +112,25 @@ __global__ void k_wtile_build(const float* __restrict__ W, float* __restrict__ W
 }
 
 // wq: this lane's float4 column of the band's tile, Wt + ((x * NT) * GW + li) * 4; a relation is 8 NT GW float4s on
+// The coefficients of relation rl for this lane's block -- fetched only when the group's registers hold ANOTHER relation's
+// (`held`): the graph preparation orders a row's slots by directed relation, and an entity's edges use few relations, so
+// consecutive slots of a group mostly repeat the relation (weight fetches per slot: 0.60 on the FB15k-237 minibatch, 0.07 /
+// 0.06 / 0.02 on the 272,115 / 141,442 / 483,142-edge training graphs; before round 5 every slot fetched its 28 registers
+// of coefficients through L1: 420 MB per launch at the minibatch, 7.8 GB at 272 k edges).  The norm changes per slot.
 template <int SD, int GW>
-__device__ __forceinline__ void load_w(const float4* __restrict__ wq, int rl, float nr, SlotRegs<SD>& r) {
+__device__ __forceinline__ void load_w(const float4* __restrict__ wq, int rl, float nr, SlotRegs<SD>& r, int& held) {
   constexpr int NT = nt_of(SD);
-  const float4* wp = wq + (size_t)rl * (8 * NT * GW);
+  if (rl != held) {
+    const float4* wp = wq + (size_t)rl * (8 * NT * GW);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float4 q = wp[t * GW];
-    r.w[4 * t] = q.x;
-    if (4 * t + 1 < SD * SD) r.w[4 * t + 1] = q.y;
-    if (4 * t + 2 < SD * SD) r.w[4 * t + 2] = q.z;
-    if (4 * t + 3 < SD * SD) r.w[4 * t + 3] = q.w;
+    for (int t = 0; t < NT; ++t) {
+      const float4 q = wp[t * GW];
+      r.w[4 * t] = q.x;
+      if (4 * t + 1 < SD * SD) r.w[4 * t + 1] = q.y;
+      if (4 * t + 2 < SD * SD) r.w[4 * t + 2] = q.z;
+      if (4 * t + 3 < SD * SD) r.w[4 * t + 3] = q.w;
+    }
+    held = rl;
   }
   r.nr = nr;
 }
@@ -278,24 +286,27 @@ __device__ __forceinline__ void wg_long_sum(const RowsArgs& a, int beg, int end,
   int my_pv, my_rl, nx_pv = 0, nx_rl = 0;
   float my_nr, nx_nr = 0.0f;
   tile_idx(beg, my_pv, my_rl, my_nr);
-  FloatN<SD> xcur = load_x<SD>(a, __shfl(my_pv, G, 64), col);
+  // group G takes the SPG CONSECUTIVE slots G SPG .. of every tile (a run of one relation stays inside a group; the sums
+  // below go by slot index, whichever group computed the message)
+  FloatN<SD> xcur = load_x<SD>(a, __shfl(my_pv, G * T::SPG, 64), col);
+  SlotRegs<SD> r0;
+  int held = -1;                                  // relation whose coefficients r0 holds
   for (int c0 = beg; c0 < end; c0 += T::TS) {
     // ---- phase 1: the tile's messages
     const bool more = c0 + T::TS < end;
 #pragma unroll
     for (int u = 0; u < T::SPG; ++u) {
-      const int s0 = G + T::NGW * u;
+      const int s0 = G * T::SPG + u;
       const int rl0 = __shfl(my_rl, s0, 64);
       const float nr0 = __shfl(my_nr, s0, 64);
       // (the memory counter retires loads in issue order: what a step waits for -- its weights -- is requested FIRST,
       // what may stay in flight -- the next slot's inputs, the next tile's indices -- behind it)
-      SlotRegs<SD> r0;
       const bool live = c0 + s0 < end;           // (group-uniform; a dead slot has index 0: valid addresses)
-      if (live) load_w<SD, GW>(wq, rl0, nr0, r0);
+      if (live) load_w<SD, GW>(wq, rl0, nr0, r0, held);
       if (u == 0 && more) tile_idx(c0 + T::TS, nx_pv, nx_rl, nx_nr);
       FloatN<SD> xnext = xcur;
-      if (u + 1 < T::SPG) xnext = load_x<SD>(a, __shfl(my_pv, G + T::NGW * (u + 1 < T::SPG ? u + 1 : u), 64), col);
-      else if (more) xnext = load_x<SD>(a, __shfl(nx_pv, G, 64), col);
+      if (u + 1 < T::SPG) xnext = load_x<SD>(a, __shfl(my_pv, G * T::SPG + (u + 1 < T::SPG ? u + 1 : u), 64), col);
+      else if (more) xnext = load_x<SD>(a, __shfl(nx_pv, G * T::SPG, 64), col);
       if (live) {
         float y0[SD];
         slot_value<SD, BWD>(r0, xcur, y0);
@@ -480,6 +491,8 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
   row_open<SD>(a, max(vA, 0), offA, rrA);
   rrA.has_base = rrA.has_base && vA >= 0;
   FloatN<SD> xcur = load_x<SD>(a, __shfl(iA.pv, g * GW, 64), col);
+  SlotRegs<SD> r0;
+  int held = -1;                                  // relation whose coefficients r0 holds (kept across slots, rows, turns)
   for (int turn = 0; turn < nturn; ++turn) {
     turn_row(turn + 2, vC, begC, nC);
     const size_t offB = (size_t)max(vB, 0) * a.d + col;
@@ -504,8 +517,12 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
           const int s0 = g * GW + k;
           // (the memory counter retires loads in issue order: the weights this step waits for are requested FIRST, what
           // may stay in flight -- the next x, the next turn's row pieces, the indices two turns on -- behind them)
-          SlotRegs<SD> r0;
-          load_w<SD, GW>(wq, __shfl(iA.rl, s0, 64), __shfl(iA.nr, s0, 64), r0);
+          const bool live0 = c0 + k < nA;
+          {
+            const int rl0 = __shfl(iA.rl, s0, 64);
+            const float nr0 = __shfl(iA.nr, s0, 64);
+            if (live0) load_w<SD, GW>(wq, rl0, nr0, r0, held);      // (a dead slot's value is discarded below)
+          }
           FloatN<SD> xnext = xcur;
           if (k + 1 < m_u) xnext = load_x<SD>(a, __shfl(iA.pv, s0 + 1, 64), col);
           else if (c0 + GW >= n_u && nB_u > 0) xnext = load_x<SD>(a, __shfl(iB.pv, g * GW, 64), col);
@@ -516,7 +533,6 @@ __global__ void __launch_bounds__(kRowsThreads) k_block_rows(RowsArgs a) {
           }
           float y0[SD];
           slot_value<SD, BWD>(r0, xcur, y0);
-          const bool live0 = c0 + k < nA;
 #pragma unroll
           for (int i = 0; i < SD; ++i) {
             const float t0 = tot[i] + y0[i];

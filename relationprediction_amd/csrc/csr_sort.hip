@@ -4,8 +4,8 @@
 // SparseSoftmax / SparseTensorDenseMatMul / UnsortedSegmentSum kernels), and the entity / relation CSRs of the decoder
 // batch (code/decoders/bilinear_diag.py:18-25 gathers).
 //
-// Keys are vertex or relation ids (<= 22 bits), values the positions 0..n-1, so a least-significant-digit radix sort
-// with 8-bit digits needs 1-3 passes.  Everything is a deterministic function of the input (no float or order-
+// Keys are vertex or relation ids, or (vertex, directed relation) pairs (< 2^31), values the positions 0..n-1, so a
+// least-significant-digit radix sort with 8-bit digits needs 1-4 passes.  Everything is a deterministic function of the input (no float or order-
 // dependent atomics), which is what makes the fp32 sums downstream bitwise reproducible.
 //
 // One pass = two launches, for up to two independent sorts at once (grid.y picks the job):
@@ -198,13 +198,13 @@ size_t sort_table_elems(size_t n) {
 }
 
 // Stable sort of up to two independent (key, position) arrays by key, on the context's current stream.
-// keys < 2^24 (max_key bounds the passes); key_tmp / val_tmp: scratch of n elements; the result lands in key_out /
+// keys < 2^31 (max_key bounds the passes); key_tmp / val_tmp: scratch of n elements; the result lands in key_out /
 // val_out (val = original positions, in key order, ties in position order); pos_out (nullable) = its inverse.
 rgcn_status sort_pairs(rgcn_ctx* c, const char* tag, int njobs, const SortSpec* specs) {
   if (njobs < 1 || njobs > 2) RGCN_FAIL(c, RGCN_ERR_INVALID, "internal: sort_pairs takes one or two jobs");
   int passes[2] = {0, 0}, max_passes = 0, max_blocks = 0;
   for (int k = 0; k < njobs; ++k) {
-    if (specs[k].n < 0 || specs[k].max_key >= (1u << 24)) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "internal: sort key range");
+    if (specs[k].n < 0 || specs[k].max_key >= (1u << 31)) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "internal: sort key range");
     passes[k] = specs[k].n > 0 ? passes_for(specs[k].max_key) : 0;
     if (passes[k] > max_passes) max_passes = passes[k];
     const int nb = (int)((specs[k].n + kSortItems - 1) / kSortItems);

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kScanThreads) k_exscan(ScanJobs jobs) {
 __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
                        const int32_t* __restrict__ owner, int rank, uint32_t* keyv,
                        uint32_t* keyr, int count_degrees, int32_t* indeg, int32_t* outdeg,
-                       int32_t* errflag, int32_t* small_counters) {
+                       int32_t* errflag, int32_t* small_counters, uint32_t vmul) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // one GPU: the degrees are overwritten row by row (k_ptrs reads them off the sorted rows), only the long / giant row
   // counters need a zero before k_ptrs counts into them -- no memset launch
@@ -114,8 +114,12 @@ __global__ void k_keys(const int32_t* __restrict__ tri, int E, int V, int R,
     }
   }
   bool owned = ok && owner[r] == rank;
-  keyv[i] = owned ? (uint32_t)(fwd ? o : s) : (uint32_t)V;   // incidence i sits at this vertex
-  keyr[i] = owned ? (uint32_t)(fwd ? r : R + r) : (uint32_t)(2 * R);
+  // incidence i sits at this vertex.  vmul = 2R: the key also carries the directed relation, so that a row's slots come
+  // out ordered by relation (runs of equal relations let the destination-major layer kernel keep a relation's
+  // coefficients in registers); vmul = 1 (key range too wide for that): by vertex alone, ties in incidence order
+  const uint32_t rel2 = (uint32_t)(fwd ? r : R + r);
+  keyv[i] = owned ? (uint32_t)(fwd ? o : s) * vmul + (vmul > 1 ? rel2 : 0u) : (uint32_t)V * vmul;
+  keyr[i] = owned ? rel2 : (uint32_t)(2 * R);
 }
 
 __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int n, uint32_t x) {
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
                                                int32_t* giant_rows, int32_t* giant_first, int32_t* giant_cnt,
                                                int32_t* piece_row, int32_t* piece_k, int32_t* ngiant, int giant_cap,
                                                int piece_cap, int32_t* rel_ptr, int32_t* chunk_ptr,
-                                               uint32_t* row_key, int32_t* has_dir) {
+                                               uint32_t* row_key, int32_t* has_dir, uint32_t vmul) {
   if (blockIdx.x == 0) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
@@ -181,15 +185,15 @@ __global__ void __launch_bounds__(1024) k_ptrs(const uint32_t* __restrict__ keyv
   }
   const int v = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
   if (v > V) return;
-  const int beg = lower_bound_u32(keyv_s, M, (uint32_t)v);
+  const int beg = lower_bound_u32(keyv_s, M, (uint32_t)v * vmul);
   row_ptr[v] = beg;
   if (v == V) return;
-  const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1));
+  const int end = lower_bound_u32(keyv_s, M, (uint32_t)(v + 1) * vmul);
   if (row_key != nullptr) row_key[v] = end - beg > kLongRow ? (uint32_t)(kLongRow + 1) : (uint32_t)(kLongRow - (end - beg));
   if (degrees_from_rows || has_dir != nullptr) {
-    // row v holds every LOCAL incidence of v, the stable sort put the incidences with index < E (edges arriving at v:
-    // forward-direction messages) first -> their count = position of the first index >= E.  All relations local: that
-    // is the in-degree
+    // row v holds every LOCAL incidence of v, the incidences with index < E (edges arriving at v: forward-direction
+    // messages, directed relation < R) first -- by the stable sort's tie order, or by the relation part of the key -> their
+    // count = position of the first index >= E.  All relations local: that is the in-degree
     int lo = beg, hi = end;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -560,6 +564,9 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
   g.pf_valid = false;
   g.units_host = -1;
   c->fwd_done = false;
+  // the vertex key carries the directed relation when (V + 1) 2R fits the sort's key range (every dataset of the reference;
+  // otherwise rows keep incidence order: the layer kernels find fewer runs, nothing else changes)
+  const uint32_t vmul = (uint64_t)(V + 1) * (2 * (uint64_t)R) < (1ull << 31) ? (uint32_t)(2 * R) : 1u;
   const bool zero_in_keys = c->world == 1 && E > 0;      // (sharded: the degree counters are atomically added to)
   if (!zero_in_keys) RGCN_HIP(c, hipMemsetAsync(g.counters, 0, g.counters_bytes, c->stream));
   const int T = 256;
@@ -568,11 +575,11 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
       ProfScope ps(c, "prep_keys", 12.0 * E + 16.0 * M, 0);
       hipLaunchKernelGGL(k_keys, dim3((M + T - 1) / T), dim3(T), 0, c->stream, tri, E, V, R, g.owner,
                          c->rank, g.keyv, g.keyr, c->world > 1 ? 1 : 0, g.indeg, g.outdeg, g.errflag,
-                         zero_in_keys ? g.nlong : (int32_t*)nullptr);
+                         zero_in_keys ? g.nlong : (int32_t*)nullptr, vmul);
     }
     // incidences by vertex (-> permv, pos) and messages by directed relation (-> permr), in the same launches
     SortSpec sp[2];
-    sp[0] = SortSpec{g.keyv, g.keyv_s, g.permv, g.keyv_t, g.valv, g.pos, g.tablev, (int64_t)M, (uint32_t)V};
+    sp[0] = SortSpec{g.keyv, g.keyv_s, g.permv, g.keyv_t, g.valv, g.pos, g.tablev, (int64_t)M, (uint32_t)V * vmul};
     sp[1] = SortSpec{g.keyr, g.keyr_s, g.permr, g.keyr_t, g.valr, nullptr, g.tabler, (int64_t)M, (uint32_t)(2 * R)};
     RGCN_TRY(sort_pairs(c, "prep_sort", 2, sp));
   }
@@ -582,7 +589,7 @@ rgcn_status graph_build(rgcn_ctx* c, const int32_t* tri, int64_t E64) {
                        g.permv, E, c->world > 1 ? 0 : 1, g.indeg, g.outdeg, M, V, 2 * R, g.chunk, g.row_ptr, g.long_rows,
                        g.nlong, g.long_cap,
                        g.giant_on ? kGiantRow : 0x7fffffff, g.giant_rows, g.giant_first, g.giant_cnt, g.piece_row,
-                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr, g.row_key, g.has_dir);
+                       g.piece_k, g.ngiant, g.giant_cap, g.piece_cap, g.rel_ptr, g.chunk_ptr, g.row_key, g.has_dir, vmul);
   }
   if (g.row_key != nullptr) {
     // rows by descending length (stable, one 8-bit pass of the library's radix sort over V keys <= 33)

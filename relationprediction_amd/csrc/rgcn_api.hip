@@ -1122,22 +1122,11 @@ rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int
   RGCN_NEED(c);
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
   RGCN_TRY(step_begin(c, tri_dev, E));
-  // The top layer's dS = dL/dcodes * dropout_L depends on the caller's gradient and on (seed, L) only -- not on the forward
-  // pass: with the side streams on it is formed on side stream 0 beside the forward pass instead of at the head of the
-  // backward pass (a 58 MB pass, 13 us of the critical path at FB15k-237 size).
-  const float* ds_ready = nullptr;
-  if (train && dcodes_dev != nullptr && c->use_aux && c->world == 1) {
-    c->fwd_train = 1; c->seed = seed; c->explicit_masks = false;      // what make_drop reads (fwd_begin sets the same)
-    const DropSpec ds = make_drop(c, c->L, true);
-    if (ds.mode != DROP_NONE) {
-      StreamScope side(c, 0);
-      RGCN_TRY(scale_dropout(c, dcodes_dev, c->dsbuf[c->L & 1], ds));
-      ds_ready = c->dsbuf[c->L & 1];
-    }
-  }
+  // (Round 5 tried forming the top layer's dS = dL/dcodes * dropout_L -- which depends on the caller's gradient and the seed
+  // only -- on a side stream beside the forward pass: 0.567 ms per step against 0.559 on the same box.  A fork + join costs
+  // the main stream more than the 13 us pass it hides.)
   RGCN_TRY(forward_all(c, train, seed, nullptr));
-  RGCN_TRY(stream_join(c, 0));
-  RGCN_TRY(backward_all(c, dcodes_dev, ds_ready));
+  RGCN_TRY(backward_all(c, dcodes_dev));
   return step_end(c);
 }
 

@@ -188,12 +188,15 @@ def test_graph_prep_degrees_and_csr(native):
 
 
 @pytest.mark.parametrize("V,R,E", [(97, 5, 400), (14541, 237, 15000), (40943, 18, 10000), (300, 1345, 2049),
-                                   (70000, 3, 5000), (14541, 237, 38001), (90000, 40, 700000)])
+                                   (70000, 3, 5000), (14541, 237, 38001), (90000, 40, 700000), (14951, 1345, 60000),
+                                   (6000000, 200, 3000)])
 def test_graph_prep_orderings_equal_a_stable_sort(native, V, R, E):
-    """the library's own sort (csr_sort.hip) against numpy's stable argsort: incidences by vertex and messages by
-    directed relation, ties in index order -- bit-exact (integer work), incl. more than one 2048-item block, a key
-    range above 16 bits (three radix passes), hub rows, and 1.4 M items (684 blocks: the column-prefix pass of large
-    sorts, k_sort_prefix)"""
+    """the library's own sort (csr_sort.hip) against numpy's stable argsort: incidences by (vertex, directed relation)
+    -- a row's slots in relation order, so that the layer kernels find runs of one relation -- and messages by directed
+    relation, ties in index order -- bit-exact (integer work), incl. more than one 2048-item block, key ranges of three and
+    four radix passes (FB15k's 14,951 x 2,690 pairs), hub rows, 1.4 M items (684 blocks: the column-prefix pass of large
+    sorts, k_sort_prefix), and an entity count whose pair key does not fit the sort's 31 bits (the key is then the vertex
+    alone: incidence order inside a row)"""
     rng = np.random.RandomState(V + E)
     hub = rng.randint(0, V, 8)
     s = np.where(rng.rand(E) < 0.2, hub[rng.randint(0, 8, E)], rng.randint(0, V, E))
@@ -211,7 +214,8 @@ def test_graph_prep_orderings_equal_a_stable_sort(native, V, R, E):
         eng.close()
     keyv = np.concatenate([triples[:, 2], triples[:, 0]])
     keyr = np.concatenate([triples[:, 1], R + triples[:, 1]])
-    np.testing.assert_array_equal(permv, np.argsort(keyv, kind="stable"))
+    pair_key = (V + 1) * 2 * R < 2 ** 31
+    np.testing.assert_array_equal(permv, np.argsort(keyv.astype(np.int64) * (2 * R) + keyr if pair_key else keyv, kind="stable"))
     np.testing.assert_array_equal(permr, np.argsort(keyr, kind="stable"))
     np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(keyv, minlength=V))]))
 

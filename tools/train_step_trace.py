@@ -30,6 +30,8 @@ N = len(batch) * 11                      # NegativeSampleRate 10: drawn on the d
 params = init_encoder_params(V, R, d, L, "block", nb, rng=np.random.RandomState(1))
 params["W_relation"] = np.random.RandomState(2).randn(V, d).astype(np.float32)
 eng = _native.Engine(V, R, d, L, "block", nb, keep_prob=0.8, max_edges=E)
+if os.environ.get("RGCN_STREAMS", "1") == "0":      # this script's own switch: every kernel on the main stream
+    eng.set_overlap(False)
 eng.set_params(params)
 eng.decoder_reserve(N)
 eng.optimizer_config(lr=0.01, max_grad_norm=1.0)
