@@ -745,7 +745,8 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     //   minibatch scale, one GPU, side streams on:  dW_self forked BEFORE dH is launched (MFMA beside MFMA: the second
     //       GEMM fills the slots the first leaves idle, 456 workgroups on 512, and its tail), the relation-weight kernels
     //       forked BEHIND dH, beside the row-gradient kernel (two gather kernels share the chip better than either does
-    //       with a GEMM), joined at the end of the layer: 0.553-0.556 ms per step against 0.597-0.599 as a chain;
+    //       with a GEMM), joined at the end of the layer: 0.553-0.556 ms per step against 0.597-0.599 as a chain (round 5,
+    //       same box: dW_self forked BEHIND dH instead, beside the row-gradient kernel: 0.567-0.578 against 0.541-0.547);
     //   the same inside a capture (a captured step is a chain, rgcn_capture_begin) or with the side streams off: the
     //       chain, with the one fork a replayed graph gains from -- the slab reduce + dW_self beside dH;
     //   full-graph scale or a sharded run: the relation-weight kernels on side stream 0 from the start of the layer
