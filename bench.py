@@ -156,13 +156,14 @@ class Ranks:
 
 
 # profile tag (csrc ProfScope name) -> HIP kernel name prefix in the rocprofv3 summaries
-KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, false", "gemm_self_dh": "k_gemm_bf16x3<true, true",
+# (the pre-split-weight instantiation <true, true, true, TERMS, true> serves both the NN and the NT products)
+KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, ", "gemm_self_dh": "k_gemm_bf16x3<true, ",
                  "gemm_self_dw": "k_gemm_bf16x3<false, false", "block_msg_fwd": "k_block_msg_fwd",
                  "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine",
                  "input_fwd": "k_input_fwd", "top_grad_dropout": "k_scale_dropout", "block_dw_reduce": "k_block_dw_reduce",
                  "splitk_reduce": "k_splitk_reduce", "prep_sort": "k_sort_scatter",
                  "prep_keys": "k_keys", "prep_ptrs": "k_ptrs", "prep_build_msgs": "k_build_msgs",
-                 "gemm_basis_fwd": "k_gemm_bf16x3<true, false", "gemm_basis_dz": "k_gemm_bf16x3<true, true",
+                 "gemm_basis_fwd": "k_gemm_bf16x3<true, ", "gemm_basis_dz": "k_gemm_bf16x3<true, ",
                  "gemm_basis_dw": "k_gemm_bf16x3<false, false", "basis_agg": "k_basis_agg",
                  "basis_bwd_gather": "k_basis_bwd_gather", "basis_dcoef": "k_basis_dcoef",
                  # (prefix, substring): template arguments in the middle of the name tell the instantiations apart
