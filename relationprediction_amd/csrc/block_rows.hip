@@ -92,7 +92,14 @@ constexpr int nt_of(int sd) { return (sd * sd + 3) / 4; }       // float4s per (
 // li is beyond the band).  The GW lanes of a group read their t-th float4 from ONE aligned run of 16 GW bytes: every
 // 128-byte line the vector cache fetches is used whole (the weights' own [rel][sd*sd][nb] layout gives a group 52
 // useful bytes per line touched, and the kernel ran at the vector cache's line rate: 72 us for the short rows).
-__global__ void k_wtile_build(const float* __restrict__ W, float* __restrict__ Wt, int R2, int nb, int sd2, int nt, int gw) {
+struct WtileJobs {
+  const float* W[8];
+  float* Wt[8];
+};
+// (blockIdx.y = layer: a train step rebuilds the copies of every layer with one launch)
+__global__ void k_wtile_build(WtileJobs jobs, int R2, int nb, int sd2, int nt, int gw) {
+  const float* __restrict__ W = jobs.W[blockIdx.y];
+  float* __restrict__ Wt = jobs.Wt[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one float4 of Wt
   if (i >= (int64_t)R2 * 8 * nt * gw) return;
   const int li = (int)(i % gw);
@@ -604,22 +611,35 @@ bool block_rows_available(const rgcn_ctx* c) {
   return c->kind == RGCN_KIND_BLOCK && c->nb <= 512 && c->g.d_src != nullptr && c->g.row_order != nullptr;
 }
 
-// band-tiled copy of a layer's relation weights, rebuilt when the weights changed (set_param, Adam) -- and inside every
-// captured step, whose replays follow weights the host does not see
+// band-tiled copies of the layers' relation weights, rebuilt -- every layer's, one launch -- when the weights changed
+// (set_param, Adam) and once inside every captured step, whose replays follow weights the host does not see
 static rgcn_status block_rows_refresh_weights(rgcn_ctx* c, int layer) {
-  LayerBufs& lb = c->layers[layer];
   const int gw = rows_group_width(c), nt = nt_of(c->sd);
   const int64_t n4 = (int64_t)2 * c->R * 8 * nt * gw;
-  if (!lb.wtile) {
+  LayerBufs& mine = c->layers[layer];
+  if (!mine.wtile) {
     if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "internal: the band-tiled weight copy must exist before a capture");
-    RGCN_HIP(c, hipMalloc((void**)&lb.wtile, sizeof(float) * 4 * (size_t)n4));
+    RGCN_HIP(c, hipMalloc((void**)&mine.wtile, sizeof(float) * 4 * (size_t)n4));
   }
-  if (!c->capturing && lb.wtile_version == c->weights_version) return RGCN_OK;
-  ProfScope ps(c, "block_wtile_build", 4.0 * (2.0 * c->R * c->sd * c->sd * c->nb) + 16.0 * n4, 0);
-  hipLaunchKernelGGL(k_wtile_build, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, lb.wrel, lb.wtile,
-                     2 * c->R, c->nb, c->sd * c->sd, nt, gw);
-  RGCN_HIP(c, hipGetLastError());
-  lb.wtile_version = c->capturing ? ~0ull : c->weights_version;
+  if (c->capturing ? c->wtile_fresh : mine.wtile_version == c->weights_version) return RGCN_OK;
+  c->wtile_fresh = true;
+  for (int l0 = 1; l0 <= c->L; l0 += 8) {
+    WtileJobs jobs;
+    int nj = 0;
+    for (int l = l0; l <= c->L && nj < 8; ++l) {
+      LayerBufs& lb = c->layers[l];
+      if (!lb.wtile) continue;
+      jobs.W[nj] = lb.wrel; jobs.Wt[nj] = lb.wtile;
+      lb.wtile_version = c->capturing ? ~0ull : c->weights_version;
+      ++nj;
+    }
+    if (nj == 0) continue;
+    for (int k = nj; k < 8; ++k) { jobs.W[k] = jobs.W[0]; jobs.Wt[k] = jobs.Wt[0]; }
+    ProfScope ps(c, "block_wtile_build", nj * (4.0 * (2.0 * c->R * c->sd * c->sd * c->nb) + 16.0 * n4), 0);
+    hipLaunchKernelGGL(k_wtile_build, dim3((unsigned)((n4 + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, jobs,
+                       2 * c->R, c->nb, c->sd * c->sd, nt, gw);
+    RGCN_HIP(c, hipGetLastError());
+  }
   return RGCN_OK;
 }
 

@@ -552,29 +552,33 @@ hipError_t launch_form(rgcn_ctx* c, bool a_kc, bool b_kc, const XArgs& g) {
   return launch_one<false, false, VEC, TERMS>(c, g);
 }
 
-// B (k, n) of a contraction -- stored [n][k] (B_KC) or [k][n] -- split ONCE into the three bf16 planes, laid out so that
+// B (k, n) of a contraction -- stored [n][k] (b_kc) or [k][n] -- split ONCE into the three bf16 planes, laid out so that
 // lane (li, h) of the wave that owns 32-column tile nt finds the eight k = 16 kt + 8 h .. + 7 of column 32 nt + li of
 // plane p in ONE aligned 16-byte word: F[kt][nt][p][h][li].  Zero beyond K and N.  The arithmetic is split_level's, the
-// word order load_frag's: the B_PRE kernel feeds the MFMAs bit for bit what the staged path does.
-template <bool B_KC>
-__global__ void __launch_bounds__(256) k_presplit_b(const float* __restrict__ B, int ldb, int K, int N, int ktiles, int nt32,
-                                                    u32x4* __restrict__ F, size_t strideB, size_t strideF) {
+// word order load_frag's: the B_PRE kernel feeds the MFMAs bit for bit what the staged path does.  Several tables per
+// launch (blockIdx.y): a train step rebuilds every weight's tables -- W_self of every layer in both orientations, the
+// basis tensors -- with one launch when the optimizer has moved the weights.
+struct PresplitJobs {
+  PresplitJob j[8];
+};
+__global__ void __launch_bounds__(256) k_presplit_b(PresplitJobs jobs) {
+  const PresplitJob job = jobs.j[blockIdx.y];
+  const int ktiles = (job.K + BK - 1) / BK, nt32 = 4 * ((job.N + BN - 1) / BN);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= ktiles * nt32 * 64) return;
-  B += (size_t)blockIdx.y * strideB;
-  F += (size_t)blockIdx.y * strideF;
+  const float* __restrict__ B = job.B;
   const int li = i & 31, h = (i >> 5) & 1, nt = (i >> 6) % nt32, kt = (i >> 6) / nt32;
   const int n = 32 * nt + li, k0 = 16 * kt + 8 * h;
   f32x4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};      // k0 .. k0 + 3, k0 + 4 .. k0 + 7
-  if (n < N) {
+  if (n < job.N) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = k0 + q;
-      const float x = k < K ? (B_KC ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.0f;
+      const float x = k < job.K ? (job.b_kc ? B[(size_t)n * job.ldb + k] : B[(size_t)k * job.ldb + n]) : 0.0f;
       if (q < 4) lo4[q] = x; else hi4[q - 4] = x;
     }
   }
-  u32x4* dst = F + ((size_t)(kt * nt32 + nt) * 6 + h) * 32 + li;
+  u32x4* dst = reinterpret_cast<u32x4*>(job.F) + ((size_t)(kt * nt32 + nt) * 6 + h) * 32 + li;
 #pragma unroll
   for (int level = 0; level < 3; ++level) {
     u32x4 w;
@@ -595,20 +599,24 @@ size_t gemm_bfrag_words(int K, int N) {      // 16-byte words of one operand's f
   return (size_t)((K + BK - 1) / BK) * (4 * ((N + BN - 1) / BN)) * 192;
 }
 
-// F = the fragment table of B (k, n) for the B_PRE kernel; `groups` operands strideB floats / strideF words apart
-rgcn_status gemm_presplit_b(rgcn_ctx* c, const float* B, bool b_kc, int K, int N, int ldb, void* F, int groups,
-                            size_t strideB, size_t strideF) {
-  const int ktiles = (K + BK - 1) / BK, nt32 = 4 * ((N + BN - 1) / BN);
-  const int threads = ktiles * nt32 * 64;
-  ProfScope ps(c, "gemm_presplit_b", groups * (4.0 * K * N + 16.0 * 3 * threads), 0);
-  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)groups), block(256);
-  if (b_kc)
-    hipLaunchKernelGGL((k_presplit_b<true>), grid, block, 0, c->stream, B, ldb, K, N, ktiles, nt32,
-                       reinterpret_cast<u32x4*>(F), strideB, strideF);
-  else
-    hipLaunchKernelGGL((k_presplit_b<false>), grid, block, 0, c->stream, B, ldb, K, N, ktiles, nt32,
-                       reinterpret_cast<u32x4*>(F), strideB, strideF);
-  RGCN_HIP(c, hipGetLastError());
+// the fragment tables of n operands (PresplitJob: B (k, n), its storage form and leading dimension, the table), eight per launch
+rgcn_status gemm_presplit_b(rgcn_ctx* c, const PresplitJob* jobs, int n) {
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    PresplitJobs pj;
+    int nj = 0, max_threads = 0;
+    double bytes = 0;
+    for (; nj < 8 && j0 + nj < n; ++nj) {
+      pj.j[nj] = jobs[j0 + nj];
+      const PresplitJob& q = pj.j[nj];
+      const int threads = ((q.K + BK - 1) / BK) * (4 * ((q.N + BN - 1) / BN)) * 64;
+      if (threads > max_threads) max_threads = threads;
+      bytes += 4.0 * q.K * q.N + 16.0 * 3 * threads;
+    }
+    for (int k = nj; k < 8; ++k) pj.j[k] = pj.j[0];
+    ProfScope ps(c, "gemm_presplit_b", bytes, 0);
+    hipLaunchKernelGGL(k_presplit_b, dim3((unsigned)((max_threads + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, pj);
+    RGCN_HIP(c, hipGetLastError());
+  }
   return RGCN_OK;
 }
 

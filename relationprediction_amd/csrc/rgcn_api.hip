@@ -516,6 +516,8 @@ static rgcn_status param_download(rgcn_ctx* c, const Param& p, const float* src,
 static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks_host) {
   if (!c->g.ready) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_forward before rgcn_set_graph");
   c->fwd_done = false;
+  c->frag_fresh = false;
+  c->wtile_fresh = false;
   c->fwd_train = train ? 1 : 0;
   c->seed = seed;
   c->explicit_masks = false;
@@ -553,26 +555,38 @@ static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
 // cover) the two-kernel form: relation-major message kernel + k_combine.
 static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 1 && block_rows_available(c); }
 
-// Fragment table of a weight that is the B operand of a contraction, rebuilt when the weights changed (set_param, Adam)
-// -- and inside every captured step, whose replays follow weights the host does not see.  Returns nullptr when the
-// dense contractions run on the fp32 MFMA (no split, nothing to pre-split).
-static rgcn_status weight_fragments(rgcn_ctx* c, void* table, uint64_t* version, const float* W, bool b_kc, int K, int N,
-                                    int ldb, int groups, size_t strideW, const void** out) {
-  *out = nullptr;
-  if (c->gemm_mode == 0 || table == nullptr) return RGCN_OK;
-  if (c->capturing || *version != c->weights_version) {
-    RGCN_TRY(gemm_presplit_b(c, W, b_kc, K, N, ldb, table, groups, strideW, gemm_bfrag_words(K, N)));
-    *version = c->capturing ? ~0ull : c->weights_version;
+// Fragment tables of the weights that are the B operand of a contraction (W_self of every layer in both orientations, the
+// basis tensors), rebuilt -- all of them, one launch -- when the weights changed (set_param, Adam) and once inside every
+// captured step, whose replays follow weights the host does not see.  Nothing to do when the dense contractions run on
+// the fp32 MFMA (no split, nothing to pre-split).
+static rgcn_status refresh_weight_fragments(rgcn_ctx* c) {
+  if (c->gemm_mode == 0) return RGCN_OK;
+  if (c->capturing ? c->frag_fresh : c->frag_version == c->weights_version) return RGCN_OK;
+  std::vector<PresplitJob> jobs;
+  const int d = c->d, Bd = c->B * c->d;
+  for (int l = 1; l <= c->L; ++l) {
+    LayerBufs& lb = c->layers[l];
+    if (!lb.wself_nn || !lb.wself_nt) continue;
+    jobs.push_back(PresplitJob{lb.wself, lb.wself_nn, d, d, d, 0});      // H . W_self:      B (k, n) = W[k][n]
+    jobs.push_back(PresplitJob{lb.wself, lb.wself_nt, d, d, d, 1});      // dS . W_self^T:   B (k, n) = W[n][k]
+    if (c->kind == RGCN_KIND_BASIS && lb.wrel_nn && lb.wrel_nt)
+      for (int g = 0; g < 2; ++g) {
+        const float* W = lb.wrel + (size_t)g * Bd * d;                   // W'_dir [B.d, d]
+        jobs.push_back(PresplitJob{W, static_cast<char*>(lb.wrel_nn) + 16 * g * gemm_bfrag_words(Bd, d), d, Bd, d, 0});
+        jobs.push_back(PresplitJob{W, static_cast<char*>(lb.wrel_nt) + 16 * g * gemm_bfrag_words(d, Bd), d, d, Bd, 1});
+      }
   }
-  *out = table;
+  if (!jobs.empty()) RGCN_TRY(gemm_presplit_b(c, jobs.data(), (int)jobs.size()));
+  c->frag_fresh = true;
+  c->frag_version = c->capturing ? ~0ull : c->weights_version;
   return RGCN_OK;
 }
 // the self-loop products: one group, W_self as the pre-split B operand (forward: [k][n]; dH: used transposed, [n][k])
 static rgcn_status self_loop_batch(rgcn_ctx* c, int l, bool transposed, GemmBatch* b) {
-  LayerBufs& lb = c->layers[l];
   *b = GemmBatch();
-  return weight_fragments(c, transposed ? lb.wself_nt : lb.wself_nn, transposed ? &lb.wself_nt_version : &lb.wself_nn_version,
-                          lb.wself, transposed, c->d, c->d, c->d, 1, 0, &b->bfrag);
+  RGCN_TRY(refresh_weight_fragments(c));
+  if (c->gemm_mode != 0) b->bfrag = transposed ? c->layers[l].wself_nt : c->layers[l].wself_nn;
+  return RGCN_OK;
 }
 
 // Basis kind: the two direction groups of a batched GEMM over the (row, direction) units of the current graph; the
@@ -649,8 +663,8 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(wait_gather(c));
     RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
     GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
-    RGCN_TRY(weight_fragments(c, c->layers[l].wrel_nn, &c->layers[l].wrel_nn_version, c->layers[l].wrel, false, Bd, d, d, 2,
-                              (size_t)Bd * d, &gb.bfrag));
+    RGCN_TRY(refresh_weight_fragments(c));
+    if (c->gemm_mode != 0) gb.bfrag = c->layers[l].wrel_nn;
     gb.strideBfrag = gemm_bfrag_words(Bd, d);
     RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
                       c->aggbuf, d, 1, &gb, basis_unit_share(c)));
@@ -832,7 +846,8 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(self_dh());
     // dZc_dir = Dc_dir . W'_dir^T   ([units, d] x [d, B.d], two groups)
     GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
-    RGCN_TRY(weight_fragments(c, lb.wrel_nt, &lb.wrel_nt_version, lb.wrel, true, d, Bd, d, 2, (size_t)Bd * d, &gm.bfrag));
+    RGCN_TRY(refresh_weight_fragments(c));
+    if (c->gemm_mode != 0) gm.bfrag = lb.wrel_nt;
     gm.strideBfrag = gemm_bfrag_words(d, Bd);
     RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, &gm,
                       basis_unit_share(c)));
@@ -1794,7 +1809,8 @@ rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* c, int32_t tb, int32_t M, int32_t
     if (hipMalloc(&F, 16 * gemm_bfrag_words(K, N)) != hipSuccess) { s = RGCN_ERR_NOMEM; break; }
     if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
     if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
-    if ((s = gemm_presplit_b(c, B, tb != 0, K, N, tb ? K : N, F)) != RGCN_OK) break;
+    const PresplitJob pj{B, F, tb ? K : N, K, N, tb ? 1 : 0};
+    if ((s = gemm_presplit_b(c, &pj, 1)) != RGCN_OK) break;
     GemmBatch gb;
     gb.bfrag = F;
     s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);

@@ -166,7 +166,6 @@ struct LayerBufs {
   // the exact split, in fragment order), rebuilt when the weights change: W_self for H.W_self (nn) and dS.W_self^T (nt);
   // basis kind: W'_dir for Zc.W' (nn) and Dc.W'^T (nt), two groups each.  Split arithmetic only (rgcn_set_gemm_mode 6 / 9).
   void *wself_nn = nullptr, *wself_nt = nullptr, *wrel_nn = nullptr, *wrel_nt = nullptr;
-  uint64_t wself_nn_version = ~0ull, wself_nt_version = ~0ull, wrel_nn_version = ~0ull, wrel_nt_version = ~0ull;
   // BLOCK, destination-major banded layer kernel (block_rows.hip): band-tiled copy of wrel,
   // [2R][8 bands][ceil(sd*sd/4)][GW lanes][4], allocated at first use
   float* wtile = nullptr;
@@ -390,6 +389,9 @@ struct rgcn_ctx {
   int msg_block = 0, msg_slots = 0;      // k_msg launch geometry
 
   // forward/backward state
+  uint64_t frag_version = ~0ull;         // weights_version the weight fragment tables (LayerBufs::wself_nn ...) were built from
+  bool frag_fresh = false;               // ... built since the last rgcn_forward_begin (captured steps rebuild once per step)
+  bool wtile_fresh = false;              // the same for the band-tiled block weights (LayerBufs::wtile)
   bool fwd_done = false;
   int fwd_train = 0;
   uint64_t seed = 0;
@@ -491,8 +493,12 @@ struct GemmBatch {
   size_t strideBfrag = 0;
 };
 size_t gemm_bfrag_words(int K, int N);
-rgcn_status gemm_presplit_b(rgcn_ctx* c, const float* B, bool b_kc, int K, int N, int ldb, void* F, int groups = 1,
-                            size_t strideB = 0, size_t strideF = 0);
+struct PresplitJob {
+  const float* B;      // the operand B (k, n): stored [n][k] (b_kc) or [k][n], leading dimension ldb
+  void* F;             // its fragment table, gemm_bfrag_words(K, N) 16-byte words
+  int ldb, K, N, b_kc;
+};
+rgcn_status gemm_presplit_b(rgcn_ctx* c, const PresplitJob* jobs, int n);
 
 // C[M,N] (ldc) = A(m,k) . B(k,n).  a_kc: A stored [m][k] (k contiguous, lda) else [k][m];
 // b_kc: B stored [n][k] (k contiguous, ldb) else [k][n].  split_k > 1 writes partial slabs to
