@@ -8,7 +8,7 @@
 // block_msgs.hip + k_combine, moves 2 x 60 MB per layer pass that way at FB15k-237 minibatch size, 2 x 1.1 GB at the
 // 272,115-edge training graph).
 //
-// Decomposition (the one DESIGN section 4 argued away on an estimate and round 3's block_spmm.hip did NOT try):
+// Decomposition:
 //   * the row is cut into EIGHT column bands of nb/8 blocks, band x handled by the workgroups with blockIdx % 8 == x,
 //     i.e. by the workgroups the dispatcher places on XCD x: that XCD touches 1/8 of every relation's weights
 //     (0.6 MB at FB15k-237: L2-resident) and 1/8 of every gathered row (250 bytes; the band of the whole [V,d] operand

@@ -70,8 +70,8 @@ __device__ __forceinline__ void combine_epilogue(const CombineArgs& a, size_t of
 // dropout(base) + add for one vector of one row
 template <int VEC>
 __device__ __forceinline__ void combine_prologue(const CombineArgs& a, int v, size_t off, float (&acc)[VEC]) {
-  // no fused multiply-add across "dropout scale, then add": the GEMM's fused epilogue computes the same expression
-  // and both must round alike (the two paths are held bitwise equal by tests/test_gpu_parity.py)
+  // no fused multiply-add across "dropout scale, then add": the single-pass layer kernel (block_rows.hip) computes the
+  // same expression and both must round alike (the two forms are held bitwise equal by tests/test_gpu_parity.py)
 #pragma clang fp contract(off)
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
@@ -108,7 +108,7 @@ constexpr int kLongBlocksMin = 64;  // extra workgroups of the combine grid that
 // (lane q adds the slots beg + q, beg + q + 8, ... in increasing order), THREADS / 128 of them physical
 // (threadIdx.x >> 7), each carrying VL = 8 / (THREADS / 128) virtual ones side by side (16 loads in flight per thread
 // either way); the eight partial sums are then added in lane order ((0 + 1) + 2) ... -- the same arithmetic whatever
-// THREADS is, and the one the GEMM's fused epilogue uses.  The result is valid in the threads with sl == 0 (and
+// THREADS is, and the one the single-pass layer kernel uses.  The result is valid in the threads with sl == 0 (and
 // cidx < nvec).  red: [(THREADS / 128 - 1) * VL][128 * VEC] floats of LDS.
 template <int VEC, int THREADS>
 __device__ __forceinline__ void sum_long_row(const float* __restrict__ msg, int d, int nvec, int cidx, int beg, int end,

@@ -883,7 +883,7 @@ static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
 static rgcn_status bwd_end(rgcn_ctx* c) {
   if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
   // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
-  // (form 3 on one GPU: the bottom layer's row-gradient kernel left the column sums of its rows as partials)
+  // (single-pass block layer on one GPU: the bottom layer's row-gradient kernel left the column sums of its rows as partials)
   if (c->colsum_parts > 0) RGCN_TRY(column_sum_finish(c, c->gb_emb, c->colsum_parts, c->d));
   else RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
   c->colsum_parts = 0;
