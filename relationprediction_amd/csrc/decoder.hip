@@ -879,7 +879,7 @@ rgcn_status decoder_reserve(rgcn_ctx* c, int64_t maxN) {
   RGCN_TRY(dalloc(c, &q.slab, (size_t)q.max_chunks * d));
   RGCN_TRY(dalloc(c, &q.keyv_t, 2 * N)); RGCN_TRY(dalloc(c, &q.keyr_t, N));
   RGCN_TRY(dalloc(c, &q.tablev, sort_table_elems(2 * N))); RGCN_TRY(dalloc(c, &q.tabler, sort_table_elems(N)));
-  RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_ready, hipEventDisableTiming));
+  RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_ready, order_event_flags(c)));
   if (!c->dcodes_own) RGCN_HIP(c, hipMalloc((void**)&c->dcodes_own, sizeof(float) * V * d));
   q.maxN = maxN;
   return RGCN_OK;

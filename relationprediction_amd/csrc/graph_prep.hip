@@ -516,8 +516,8 @@ rgcn_status graph_alloc(rgcn_ctx* c, const GraphBufs* share) {
     RGCN_HIP(c, hipMemsetAsync(g.owner, 0, sizeof(int32_t) * (size_t)(c->R ? c->R : 1), c->stream));
     RGCN_HIP(c, hipMemsetAsync(g.errflag, 0, sizeof(int32_t), c->stream));
   }
-  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_ready, hipEventDisableTiming));
-  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_free, hipEventDisableTiming));
+  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_ready, order_event_flags(c)));
+  RGCN_HIP(c, hipEventCreateWithFlags(&g.ev_free, order_event_flags(c)));
   RGCN_HIP(c, hipMemsetAsync(g.row_ptr, 0, sizeof(int32_t) * (V + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.rel_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));
   RGCN_HIP(c, hipMemsetAsync(g.chunk_ptr, 0, sizeof(int32_t) * (R2 + 1), c->stream));

@@ -550,7 +550,7 @@ rgcn_status neighborhood_sample(rgcn_ctx* c, int64_t k64, uint64_t seed, int32_t
   // The draw's state is shared by every draw of the context.  Same stream: stream order.  Other stream (the driver
   // draws batch 1 on the main stream and, at once, batch 2 on the prefetch stream): wait for the previous draw's end
   // BEFORE this draw's parameters overwrite the ones its kernels still read.
-  if (!q.ev_draw) RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_draw, hipEventDisableTiming));
+  if (!q.ev_draw) RGCN_HIP(c, hipEventCreateWithFlags(&q.ev_draw, order_event_flags(c)));
   if (q.last_draw_stream != nullptr && q.last_draw_stream != st) RGCN_HIP(c, hipStreamWaitEvent(st, q.ev_draw, 0));
   if (any_full)
     RGCN_TRY(rgcn_copy_to_device_async(c, q.comp_state, q.comp_state_h.data(), (int64_t)q.ncomp, on_prefetch_stream ? 1 : 0));

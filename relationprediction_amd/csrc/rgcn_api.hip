@@ -68,6 +68,19 @@ rgcn_status stream_join(rgcn_ctx* c, int k) {
   return RGCN_OK;
 }
 
+// Side streams 0 and 1 behind ONE wait of the main stream (side 0 waits for side 1 first): where both were forked in the
+// same layer, the second wait is a packet the main stream can do without.
+static rgcn_status stream_join_both(rgcn_ctx* c) {
+  if (c->stream != c->main_stream) return RGCN_OK;
+  if (c->aux_dirty[0] && c->aux_dirty[1]) {
+    RGCN_HIP(c, hipEventRecord(c->ev_join[1], c->aux[1]));
+    RGCN_HIP(c, hipStreamWaitEvent(c->aux[0], c->ev_join[1], 0));
+    c->aux_dirty[1] = false;
+  }
+  RGCN_TRY(stream_join(c, 0));
+  return stream_join(c, 1);
+}
+
 static rgcn_status sync_all(rgcn_ctx* c) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "this call synchronises with the device: not allowed between rgcn_capture_begin and rgcn_capture_end");
   if (c->pf_stream) RGCN_HIP(c, hipStreamSynchronize(c->pf_stream));
@@ -363,10 +376,10 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     RGCN_HIP(c, acquire_stream(f.device, c->pf_priority, &c->pf_stream));
     c->aux[2] = c->pf_stream;
     for (int k = 0; k < kAuxStreams; ++k)
-      RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+      RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], order_event_flags(c)));
   }
-  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, hipEventDisableTiming));
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, order_event_flags(c)));
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, order_event_flags(c)));
   // Block kind: the destination-major banded single pass (block_rows.hip; rgcn_set_fusion 1, the default) -- no message
   // buffer, weights through L2: 39-41 us forward / 46-48 backward per layer against 57 / 75 for the two-kernel form
   // (rgcn_set_fusion 0: k_block_msg_* + k_combine, the form every other is held bitwise equal to) at FB15k-237 minibatch
@@ -515,6 +528,12 @@ static rgcn_status param_download(rgcn_ctx* c, const Param& p, const float* src,
 // ---------------------------------------------------------------- forward
 static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks_host) {
   if (!c->g.ready) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_forward before rgcn_set_graph");
+  // (a backward pass that was driven layer by layer and abandoned between layers 2 and 1 left its side kernels unjoined:
+  // they read the activations this pass overwrites.  Nothing is queued in the usual case, where every pass ended joined.)
+  if (c->stream == c->main_stream) {
+    RGCN_TRY(stream_join(c, 0));
+    RGCN_TRY(stream_join(c, 1));
+  }
   c->fwd_done = false;
   c->frag_fresh = false;
   c->wtile_fresh = false;
@@ -752,6 +771,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
     return gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
                     c->self_buf + (size_t)lo * d, d, 1, &sbt);
   };
+  bool defer_joins = false;
   if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
     // Row gradients: the single-pass kernel behind G = dS . W_self^T.  Relation-weight gradients (dW_r = sum n g (x) x,
     // relation-major, two row gathers per message): k_block_msg_bwd<dW only> + its slab reduce.  ONE schedule per
@@ -779,7 +799,11 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
         RGCN_TRY(block_dw_reduce(c, l));
       }
       RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
-      RGCN_TRY(stream_join(c, 0));
+      // Layer 2's side kernels read H_1, D_2 and dS_2 and write their own slabs and gradients.  Layer 1, next, overwrites
+      // none of those (its rows go to g_emb) and queues its side kernels behind them in stream order: its joins cover
+      // both layers, and the main stream saves two waits between the layers.
+      defer_joins = l == 2;
+      if (!defer_joins) RGCN_TRY(stream_join_both(c));
     } else if (minibatch) {
       RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
       {
@@ -856,7 +880,7 @@ static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
   }
   // the dW_self GEMM must be done before the next layer overwrites its dS operand / the caller
   // all-reduces gwself
-  RGCN_TRY(stream_join(c, 1));
+  if (!defer_joins) RGCN_TRY(stream_join(c, 1));
   return RGCN_OK;
 }
 
@@ -1113,8 +1137,11 @@ rgcn_status rgcn_backward(rgcn_ctx* c, const float* dcodes_host, int64_t count) 
 // graph or build them in line.  While a hipGraph is being captured, events recorded BEFORE the capture began
 // must not be waited on (the replayed graph is ordered behind everything earlier on the stream anyway).
 // keep >= 0: the graph is the edge-dropout subset (keep of the E batch edges, generator key eseed) of tri_dev.
-static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int64_t keep = -1, uint64_t eseed = 0) {
-  RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
+// fork_point: something of this step forks from its start (the decoder's batch preparation; inside a capture, the prefetch):
+// an encoder step outside a capture has no such fork and saves the main stream the packet.
+static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, bool fork_point, int64_t keep = -1,
+                              uint64_t eseed = 0) {
+  if (fork_point || c->capturing) RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
   c->step_begin_in_capture = c->capturing;
   if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E && c->g_alt.pf_keep == keep &&
       (keep < 0 || c->g_alt.pf_eseed == eseed)) {
@@ -1137,7 +1164,7 @@ rgcn_status rgcn_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, int
                              uint64_t seed, const float* dcodes_dev) {
   RGCN_NEED(c);
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
-  RGCN_TRY(step_begin(c, tri_dev, E));
+  RGCN_TRY(step_begin(c, tri_dev, E, false));
   // (Round 5 tried forming the top layer's dS = dL/dcodes * dropout_L -- which depends on the caller's gradient and the seed
   // only -- on a side stream beside the forward pass: 0.567 ms per step against 0.559 on the same box.  A fork + join costs
   // the main stream more than the 13 us pass it hides.)
@@ -1332,7 +1359,7 @@ rgcn_status rgcn_train_step_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t 
   if (c->world > 1 && !c->comm)
     RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
-  RGCN_TRY(step_begin(c, tri_dev, E));
+  RGCN_TRY(step_begin(c, tri_dev, E, true));
   return train_step_tail(c, X_dev, Y_dev, N, seed, reg_param);
 }
 
@@ -1381,7 +1408,7 @@ rgcn_status rgcn_train_step_minibatch_device(rgcn_ctx* c, const int32_t* batch_d
     RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
   if (c->dec.maxN < N) RGCN_FAIL(c, RGCN_ERR_STATE, "call rgcn_decoder_reserve(ctx, max_triples) first");
   // the message graph: adopted from the prefetch of this very (batch, keep, seed), or drawn and prepared in line
-  RGCN_TRY(step_begin(c, batch_dev, n, keep, edge_seed));
+  RGCN_TRY(step_begin(c, batch_dev, n, false, keep, edge_seed));   // (the fork point is recorded below)
   // the decoder batch: all n batch edges as positives (the dropped ones included) + their corruptions
   RGCN_TRY(negative_sample(c, batch_dev, n, negative_rate, negative_seed, x_scratch_dev, y_scratch_dev));
   // the decoder's batch preparation forks from ev_step_begin onto a side stream: it must see the sampled batch

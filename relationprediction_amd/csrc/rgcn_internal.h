@@ -428,6 +428,16 @@ struct rgcn_ctx {
 
 namespace rgcn {
 
+// Flags of the events that only ORDER this context's own streams on its own device (fork / join of the side streams, the
+// prefetched graph structures, the decoder batch, the sampler's state).  A default hipEventRecord is a barrier packet with a
+// system-scope release and acquire; what these events order is kernels of one device, each of which already carries its
+// agent-scope fences, so on one GPU the event's own fence is dropped: 0.528-0.534 ms per headline step against 0.535-0.543,
+// three interleaved runs each on one box (release-to-device scope: 0.538-0.540; tools/gpu_r5_evflag.sh).  A sharded
+// context, whose buffers other ranks' kernels read and write, keeps the default.
+inline unsigned order_event_flags(const rgcn_ctx* c) {
+  return hipEventDisableTiming | (c->world == 1 ? hipEventDisableSystemFence : 0u);
+}
+
 // Runs the launches inside its scope on side stream k, ordered after everything already queued on
 // the main stream (fork); join() makes the main stream wait for that side stream again.
 struct StreamScope {

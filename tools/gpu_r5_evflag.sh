@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 5: fence scope of the stream-ordering events (default = system-scope release per hipEventRecord; release-to-device;
+# no fence): headline step three times per setting, interleaved, then the block / capture / train-step tests under the setting
+# passed as $1 (default 2)
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+for rep in 1 2 3; do
+  for f in 0 1 2; do
+    RGCN_EVFLAG=$f timeout 300 python bench.py --steps 50 --warmup 10 --cpu-steps 0 --no-kernel-profile --no-extra-workloads --no-fp32-reference > gpurun_out/evflag_$f.json 2> gpurun_out/evflag_$f.err
+    python - <<PY
+import json
+o = json.loads(open("gpurun_out/evflag_$f.json").read().strip().splitlines()[-1])
+print("rep $rep flag $f", o["ms_per_step"])
+PY
+  done
+done
+RGCN_EVFLAG=${1:-2} timeout 1500 python -m pytest tests -m gpu -x -q -k "block or capture or train_step or minibatch or prefetch" 2>&1 | tail -5
