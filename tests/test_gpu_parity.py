@@ -681,6 +681,49 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4,
             e.close()
 
 
+def test_backward_driven_by_layers_can_be_read_and_abandoned_between_layers(native):
+    """One GPU, the phase API, minibatch schedule: the side-stream kernels of layer 2 (dW_self, the relation-weight
+    gradients) are joined into the main stream at the END OF LAYER 1 only (rgcn_api.hip, bwd_layer_partial).  A caller that
+    reads layer 2's gradients between the layers gets the finished values (the getters wait for every stream), and a
+    backward pass abandoned there does not race the next forward pass (fwd_begin joins what was left)."""
+    V, R, d, L, nb, E = 300, 12, 20, 2, 4, 2000
+    params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=21)
+    oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
+    e = native.Engine(V, R, d, L, "block", nb, max_edges=E)
+    try:
+        e.set_params(params)
+        e.set_graph(triples)
+        buf = e.to_device(dcodes)
+
+        def forward():
+            e.forward_begin(train=True, masks=masks)
+            for l in range(1, L + 1):
+                e.forward_layer_partial(l)
+                e.forward_layer_finish(l)
+            assert float(np.abs(e.codes() - oacts[-1]).max()) <= FWD_ATOL
+
+        for attempt in range(3):
+            forward()
+            e.backward_begin(buf)
+            e.backward_layer_partial(2)
+            e.backward_layer_finish(2)
+            for name in ["W_self2", "W_f2", "W_b2"]:
+                assert_close(e.get_grad(name), ograds[name], rel=2e-4, name="between the layers: " + name)
+            # ... and the pass is abandoned here: the next attempt starts with a forward pass
+        forward()
+        e.backward_begin(buf)
+        for l in range(L, 0, -1):
+            e.backward_layer_partial(l)
+            e.backward_layer_finish(l)
+        e.backward_end()
+        g = e.get_grads()
+        for name in ["W_emb", "b_emb", "W_self1", "W_self2", "W_f1", "W_b1", "W_f2", "W_b2"]:
+            assert_close(g[name], ograds[name], rel=2e-4, name=name)
+        buf.free()
+    finally:
+        e.close()
+
+
 def test_relation_sharding_basis(native):
     test_relation_sharding_with_host_exchange(native, 2, kind="basis", nb=3)
 
