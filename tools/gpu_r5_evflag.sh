@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5: fence scope of the stream-ordering events (default = system-scope release per hipEventRecord; release-to-device;
-# no fence): headline step three times per setting, interleaved, then the block / capture / train-step tests under the setting
-# passed as $1 (default 2)
+# round 5: the headline step three times per setting of RGCN_EVFLAG (read by the throw-away build of the fence-scope A/B;
+# the shipped library ignores it: three repeats), then the block / capture / train-step tests
+#
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
