@@ -954,8 +954,8 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     # a rank that never comes back (a collective one peer never joined) must not hold the caller for ever: after
-    # RGCN_BENCH_TIMEOUT seconds (default 900) the ranks are killed -- these exact processes -- and the run fails
-    limit = float(os.environ.get("RGCN_BENCH_TIMEOUT", "900"))
+    # RGCN_BENCH_TIMEOUT seconds (default 420) the ranks are killed -- these exact processes -- and the run fails
+    limit = float(os.environ.get("RGCN_BENCH_TIMEOUT", "420"))
     try:
         out0, _ = procs[0].communicate(timeout=limit)
         rcs = [procs[0].returncode] + [q.wait(timeout=60) for q in procs[1:]]
@@ -1057,10 +1057,10 @@ def main():
         import threading
 
         def give_up():
-            sys.stderr.write("bench.py rank %d: no result after %s s, giving up\n" % (rk.rank, os.environ.get("RGCN_BENCH_TIMEOUT", "900")))
+            sys.stderr.write("bench.py rank %d: no result after %s s, giving up\n" % (rk.rank, os.environ.get("RGCN_BENCH_TIMEOUT", "420")))
             sys.stderr.flush()
             os._exit(124)
-        dog = threading.Timer(float(os.environ.get("RGCN_BENCH_TIMEOUT", "900")), give_up)
+        dog = threading.Timer(float(os.environ.get("RGCN_BENCH_TIMEOUT", "420")), give_up)
         dog.daemon = True
         dog.start()
     if os.environ.get("RGCN_BENCH_IMPORT_TORCH") == "1":
