@@ -41,69 +41,14 @@
 //        conflict-free ds_read_b32 - no transposition anywhere.
 // Lane half h supplies k = 8h .. 8h+7 for BOTH operands, so the k order inside the MFMA is consistent.
 #include <cstdlib>
-#include <type_traits>
-#include <utility>
 
-#include "rgcn_internal.h"
+#include "gemm_split.h"
 
 namespace rgcn {
 
+using namespace gx;
+
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-struct XArgs {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* zeros;
-  int M, N, K;
-  int lda, ldb, ldc;
-  int k_per_split;
-  int tiles_m, tiles_n, splits;
-  int swizzle;
-  int vecC;
-  GemmBatch batch;    // groups (blockIdx.y) and their device-side extents
-  const u32x4* bfrag; // B_PRE instantiations: B pre-split into MFMA fragments (k_presplit_b), [ktiles][nt32][3][2][32]
-  int nt32;           // 32-column tiles of the fragment table (4 x tiles_n)
-};
-
-constexpr int BM = 128, BN = 128, BK = 16, NTH = 256;
-constexpr int KC_LD = 12;                 // dwords per row of a k-contiguous plane (8 + 4 pad)
-constexpr int RC_LD = 136;                // dwords per k-pair row of a row-contiguous plane (128 + 8 pad)
-constexpr int KC_PLANE = 128 * KC_LD;     // 1536 dwords
-constexpr int RC_PLANE = 8 * RC_LD;       // 1088 dwords
-constexpr int EPI_LD = BN + 4;
-
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-
-// One splitting level for the pair (v0[I0], v1[I1]): returns the bf16 pair nearest to it
-// (v_cvt_pk_bf16_f32, first element in the low half) and replaces the two floats by their residuals
-// x - bf16(x) (shift / mask / subtract).  bf16(x) agrees with x in its leading 8 significand bits, so the
-// difference is exactly representable: no rounding happens at any level and x = hi + mid + lo + (a
-// remainder below 2^-26 |x| that is zero unless all three roundings went the same way).
-// (v_dot2c_f32_bf16 against the pairs (-1, -0), (-0, -1) computes the same residuals in one instruction,
-// but it holds up the matrix pipe for ~10 cycles where a plain VALU op costs 2: tools/mfma_fill.hip.)
-// negmask (0 or 0x80000000, first level of the A operand only) splits -x instead of x: see the accumulator sign groups
-// in the kernel.
-template <int I0, int I1>
-__device__ __forceinline__ uint32_t split_level(f32x4& v0, f32x4& v1, uint32_t negmask = 0u) {
-  const float x0 = v0[I0], x1 = v1[I1];      // (copies: __builtin_bit_cast of a vector-element lvalue reads element 0)
-  const f32x2 f = {__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x0) ^ negmask),
-                   __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x1) ^ negmask)};
-  const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
-  v0[I0] = f[0] - __builtin_bit_cast(float, u << 16);
-  v1[I1] = f[1] - __builtin_bit_cast(float, u & 0xffff0000u);
-  return u;
-}
-__device__ __forceinline__ uint32_t split_last(float x0, float x1) {
-  const f32x2 f = {x0, x1};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
-}
 
 // ---- global -> registers -------------------------------------------------------------------------
 // k-contiguous operand: float4 p of thread t = 4 consecutive k of row (t + 256p)/4.
@@ -162,19 +107,6 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ X, const float
 //   row-contiguous operand, (even-k, odd-k) float4 pair, level = C / 4 for C < 8:
 //     C0..3 hi of row 0..3 (+ store plane 0 at C3)   C4..7 mid (+ store plane 1 at C7)
 //     C8 lo rows 0,1   C9 lo rows 2,3 + store plane 2   C10, C11 -
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
-// for the global loads of the tile after next that were issued at the top of the step.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 struct SplitRegs {
   u32x4 w;       // packed words waiting for their store
 };
@@ -563,7 +495,7 @@ struct PresplitJobs {
 };
 __global__ void __launch_bounds__(256) k_presplit_b(PresplitJobs jobs) {
   const PresplitJob job = jobs.j[blockIdx.y];
-  const int ktiles = (job.K + BK - 1) / BK, nt32 = 4 * ((job.N + BN - 1) / BN);
+  const int ktiles = (job.K + BK - 1) / BK, nt32 = bfrag_nt32(job.N);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= ktiles * nt32 * 64) return;
   const float* __restrict__ B = job.B;
@@ -596,7 +528,7 @@ __global__ void __launch_bounds__(256) k_presplit_b(PresplitJobs jobs) {
 }  // namespace
 
 size_t gemm_bfrag_words(int K, int N) {      // 16-byte words of one operand's fragment table
-  return (size_t)((K + BK - 1) / BK) * (4 * ((N + BN - 1) / BN)) * 192;
+  return (size_t)((K + BK - 1) / BK) * bfrag_nt32(N) * 192;
 }
 
 // the fragment tables of n operands (PresplitJob: B (k, n), its storage form and leading dimension, the table), eight per launch
@@ -608,7 +540,7 @@ rgcn_status gemm_presplit_b(rgcn_ctx* c, const PresplitJob* jobs, int n) {
     for (; nj < 8 && j0 + nj < n; ++nj) {
       pj.j[nj] = jobs[j0 + nj];
       const PresplitJob& q = pj.j[nj];
-      const int threads = ((q.K + BK - 1) / BK) * (4 * ((q.N + BN - 1) / BN)) * 64;
+      const int threads = ((q.K + BK - 1) / BK) * bfrag_nt32(q.N) * 64;
       if (threads > max_threads) max_threads = threads;
       bytes += 4.0 * q.K * q.N + 16.0 * 3 * threads;
     }
@@ -632,7 +564,10 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
   g.k_per_split = k_per_split; g.splits = splits; g.swizzle = swizzle; g.vecC = vecC;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
-  g.nt32 = 4 * g.tiles_n;
+  g.nt32 = bfrag_nt32(N);
+  // a weight on the B side: the eight-wavefront kernel (gemm_bf16x3_w8.hip), bitwise the same product
+  if (g.bfrag != nullptr && (terms == 6 || terms == 9) && knob("RGCN_GEMM_W8", 1) != 0)
+    return gemm_bf16x3_w8_launch(c, terms, M, N, K, A, lda, C, ldc, swizzle, vecC, g.batch);
   if (terms == 9) return vec ? launch_form<true, 9>(c, a_kc, b_kc, g) : launch_form<false, 9>(c, a_kc, b_kc, g);
   if (terms == 3) return vec ? launch_form<true, 3>(c, a_kc, b_kc, g) : launch_form<false, 3>(c, a_kc, b_kc, g);
   return vec ? launch_form<true, 6>(c, a_kc, b_kc, g) : launch_form<false, 6>(c, a_kc, b_kc, g);

@@ -494,7 +494,7 @@ static rgcn_status create_impl(rgcn_ctx* c) {
   // one partial row per combine workgroup (4 rows each at worst) + the second-level partials of their sum
   c->colsum_part_floats = ((V + 3) / 4 + 1024 + 2 + ((V + 3) / 4 + 1024) / 32 + 2) * d;
   RGCN_TRY(dmalloc(c, &c->colsum_part, c->colsum_part_floats));
-  RGCN_TRY(dmalloc(c, &c->zeros, 64));
+  RGCN_TRY(dmalloc(c, &c->zeros, 1024));
   RGCN_TRY(graph_alloc(c, nullptr));
   std::swap(c->g, c->g_alt);
   RGCN_TRY(graph_alloc(c, &c->g_alt));
@@ -1843,6 +1843,19 @@ rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* c, int32_t tb, int32_t M, int32_t
     s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
     if (s != RGCN_OK) break;
     if ((s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N)) != RGCN_OK) break;
+    // RGCN_GEMM_TL_FILE: the per-wavefront stamps of ONE more launch (k_gemm_w8<.., DBG_TIMELINE / DBG_FINE>), raw uint64
+    if (const char* tlf = getenv("RGCN_GEMM_TL_FILE")) {
+      const size_t tb_bytes = gemm_w8_timeline_bytes(M, N, 1);
+      if (hipMalloc(&c->debug_buf, tb_bytes) != hipSuccess) { s = RGCN_ERR_NOMEM; break; }
+      (void)hipMemsetAsync(c->debug_buf, 0, tb_bytes, c->stream);
+      s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
+      std::vector<char> hb(tb_bytes);
+      if (s == RGCN_OK) s = to_host(c, hb.data(), c->debug_buf, tb_bytes);
+      (void)hipFree(c->debug_buf);
+      c->debug_buf = nullptr;
+      if (s != RGCN_OK) break;
+      if (FILE* f = fopen(tlf, "wb")) { fwrite(hb.data(), 1, tb_bytes, f); fclose(f); }
+    }
     if (iters > 0 && avg_ms) {
       if ((s = rgcn_timer_start(c)) != RGCN_OK) break;
       for (int it = 0; it < iters && s == RGCN_OK; ++it)

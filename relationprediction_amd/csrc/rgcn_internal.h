@@ -370,7 +370,8 @@ struct rgcn_ctx {
   float* colsum_part = nullptr;
   size_t colsum_part_floats = 0;
   int32_t colsum_parts = 0;    // > 0: the last block_rows backward launch left that many [d] partial rows in colsum_part
-  float* zeros = nullptr;                // 64 zero floats (masked-lane load target of the GEMM)
+  void* debug_buf = nullptr;             // devtools builds: where k_gemm_w8<.., DBG_TIMELINE> leaves its stamps
+  float* zeros = nullptr;                // 1024 zero floats (masked-lane load target of the GEMMs; 3 KB for a masked LDS-DMA)
 
   rgcn::GraphBufs g;                     // ACTIVE graph structures
   rgcn::GraphBufs g_alt;                 // second set: next graph is prepared here beside the running step
@@ -521,6 +522,10 @@ rgcn_status gemm_f32(rgcn_ctx* c, const char* tag, bool a_kc, bool b_kc, int M, 
 hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool vec, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                               int k_per_split, int splits, int swizzle, int vecC, const GemmBatch* batch = nullptr);
+// gemm_bf16x3_w8.hip: the form for a pre-split weight on the B side (A k-contiguous with 16-byte rows, no split over K)
+hipError_t gemm_bf16x3_w8_launch(rgcn_ctx* c, int terms, int M, int N, int K, const float* A, int lda, float* C, int ldc,
+                                 int swizzle, int vecC, const GemmBatch& batch);
+size_t gemm_w8_timeline_bytes(int M, int N, int groups);
 
 // ---- block_msgs.hip
 rgcn_status block_geometry(rgcn_ctx* c);
