@@ -566,7 +566,17 @@ hipError_t gemm_bf16x3_launch(rgcn_ctx* c, int terms, bool a_kc, bool b_kc, bool
   g.tiles_n = (N + BN - 1) / BN;
   g.nt32 = bfrag_nt32(N);
   // a weight on the B side: the eight-wavefront kernel (gemm_bf16x3_w8.hip), bitwise the same product
-  if (g.bfrag != nullptr && (terms == 6 || terms == 9) && knob("RGCN_GEMM_W8", 1) != 0)
+  // (devtools knob RGCN_GEMM_W8: 0 never, 1 where the call site asks for it, 2 / 3 everywhere, >= 1000 the lab's variants)
+  const int w8 = knob("RGCN_GEMM_W8", 1);
+  bool wide = g.batch.wide != 0;
+  if (wide && g.batch.limit == nullptr) {
+    // one workgroup per CU and nothing to hide a tile's fill and its stores behind: the wide kernel wins when the launch is ONE
+    // round of tiles that fills most of the chip (FB15k-237: 228 tiles, 45.8 against 48.8 us), and loses to the two-per-CU
+    // kernel over several rounds (WN18, 640 tiles: 125 against 114 us) -- profiles/r06_gemm_w8.md
+    const long t = (long)((M + 127) / 128) * ((N + 255) / 256) * g.batch.groups;
+    wide = t <= 256 && t >= 160;
+  }
+  if (g.bfrag != nullptr && (terms == 6 || terms == 9) && (w8 >= 2 || (w8 == 1 && wide)))
     return gemm_bf16x3_w8_launch(c, terms, M, N, K, A, lda, C, ldc, swizzle, vecC, g.batch);
   if (terms == 9) return vec ? launch_form<true, 9>(c, a_kc, b_kc, g) : launch_form<false, 9>(c, a_kc, b_kc, g);
   if (terms == 3) return vec ? launch_form<true, 3>(c, a_kc, b_kc, g) : launch_form<false, 3>(c, a_kc, b_kc, g);

@@ -87,7 +87,7 @@ __device__ __forceinline__ void dma1(uint32_t voff, const u32x4* sbase, uint32_t
 }
 
 template <int TERMS, int DBG = 0>
-__global__ void __launch_bounds__(WNTH, 2) k_gemm_w8(XArgs g) {
+__global__ void __launch_bounds__(WNTH, 2) __attribute__((amdgpu_num_vgpr(192))) k_gemm_w8(XArgs g) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
   // ---- the tile of this workgroup (tiles_n counts 256-column tiles here)
@@ -410,6 +410,7 @@ hipError_t gemm_bf16x3_w8_launch(rgcn_ctx* c, int terms, int M, int N, int K, co
 #ifdef RGCN_DEVTOOLS
   // RGCN_GEMM_W8 = 1000 + DBG: the ablations and timelines of tools/gemm_w8_lab.py (mode 6 only)
   const int v = knob("RGCN_GEMM_W8", 1);
+  if (v == 4 && terms == 6) return launch_w8<6, DBG_NT_STORE>(c, g);
   if (v >= 1000 && terms == 6) {
     g.tl = reinterpret_cast<uint64_t*>(c->debug_buf);
     switch (v - 1000) {

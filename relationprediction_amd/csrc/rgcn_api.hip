@@ -605,6 +605,7 @@ static rgcn_status self_loop_batch(rgcn_ctx* c, int l, bool transposed, GemmBatc
   *b = GemmBatch();
   RGCN_TRY(refresh_weight_fragments(c));
   if (c->gemm_mode != 0) b->bfrag = transposed ? c->layers[l].wself_nt : c->layers[l].wself_nn;
+  b->wide = transposed ? 0 : 1;
   return RGCN_OK;
 }
 
@@ -685,6 +686,7 @@ static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
     RGCN_TRY(refresh_weight_fragments(c));
     if (c->gemm_mode != 0) gb.bfrag = c->layers[l].wrel_nn;
     gb.strideBfrag = gemm_bfrag_words(Bd, d);
+    gb.wide = 1;
     RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
                       c->aggbuf, d, 1, &gb, basis_unit_share(c)));
     RGCN_TRY(stream_join(c, 1));
@@ -1840,6 +1842,7 @@ rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* c, int32_t tb, int32_t M, int32_t
     if ((s = gemm_presplit_b(c, &pj, 1)) != RGCN_OK) break;
     GemmBatch gb;
     gb.bfrag = F;
+    gb.wide = 1;
     s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
     if (s != RGCN_OK) break;
     if ((s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N)) != RGCN_OK) break;

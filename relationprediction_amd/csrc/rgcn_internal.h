@@ -502,6 +502,11 @@ struct GemmBatch {
   // split over K; ignored otherwise (B itself must still be passed).  strideBfrag: 16-byte words between groups.
   const void* bfrag = nullptr;
   size_t strideBfrag = 0;
+  // with bfrag: take the 128 x 256 / eight-wavefront kernel (gemm_bf16x3_w8.hip; one workgroup holds a whole CU) instead of
+  // the 128 x 128 / four-wavefront one (two per CU, room for another kernel's workgroups beside them).  Same result bit for
+  // bit; which is faster in the step depends on what runs beside the product: the forward products
+  // run alone on the main stream (wide), the backward ones beside dW_self and the relation-weight kernels (not wide).
+  int wide = 0;
 };
 size_t gemm_bfrag_words(int K, int N);
 struct PresplitJob {
