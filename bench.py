@@ -157,13 +157,15 @@ class Ranks:
 
 # profile tag (csrc ProfScope name) -> HIP kernel name prefix in the rocprofv3 summaries
 # (the pre-split-weight instantiation <true, true, true, TERMS, true> serves both the NN and the NT products)
-KERNEL_OF_TAG = {"gemm_self_fwd": "k_gemm_bf16x3<true, ", "gemm_self_dh": "k_gemm_bf16x3<true, ",
+# (a list: the first kernel name found in the table -- the forward products run on k_gemm_w8 where the launch is one round of
+# 128 x 256 tiles, csrc/gemm_bf16x3.hip, and on the 128 x 128 kernel otherwise)
+KERNEL_OF_TAG = {"gemm_self_fwd": ["k_gemm_w8<", "k_gemm_bf16x3<true, "], "gemm_self_dh": "k_gemm_bf16x3<true, ",
                  "gemm_self_dw": "k_gemm_bf16x3<false, false", "block_msg_fwd": "k_block_msg_fwd",
                  "block_msg_bwd": "k_block_msg_bwd", "combine_fwd": "k_combine", "combine_bwd": "k_combine",
                  "input_fwd": "k_input_fwd", "top_grad_dropout": "k_scale_dropout", "block_dw_reduce": "k_block_dw_reduce",
                  "splitk_reduce": "k_splitk_reduce", "prep_sort": "k_sort_scatter",
                  "prep_keys": "k_keys", "prep_ptrs": "k_ptrs", "prep_build_msgs": "k_build_msgs",
-                 "gemm_basis_fwd": "k_gemm_bf16x3<true, ", "gemm_basis_dz": "k_gemm_bf16x3<true, ",
+                 "gemm_basis_fwd": ["k_gemm_w8<", "k_gemm_bf16x3<true, "], "gemm_basis_dz": "k_gemm_bf16x3<true, ",
                  "gemm_basis_dw": "k_gemm_bf16x3<false, false", "basis_agg": "k_basis_agg",
                  "basis_bwd_gather": "k_basis_bwd_gather", "basis_dcoef": "k_basis_dcoef",
                  # (prefix, substring): template arguments in the middle of the name tell the instantiations apart
@@ -179,6 +181,8 @@ def kernel_traffic(traffic, tag, args):
     pref = KERNEL_OF_TAG.get(tag)
     if not pref:
         return None
+    if isinstance(pref, list):
+        pref = next((p for p in pref if any(n.startswith(p) for n in traffic)), pref[-1])
     pref, sub = pref if isinstance(pref, tuple) else (pref, "")
     if tag == "block_msg_bwd":
         sub = ", true>"
@@ -378,6 +382,27 @@ def measure(workload, args, rk, steps, warmup, full):
         comm_buf.upload(v)
         eng.comm_allreduce_sum(comm_buf, world)
         return comm_buf.download(np.float32, (world,))
+    if world > 1:
+        # First contact with a multi-GPU node must diagnose itself: the collective library has to SEE `world` ranks, and no two
+        # ranks may sit on one device (a mis-set LOCAL_RANK / HIP_VISIBLE_DEVICES gives N processes on GPU 0 that "scale"
+        # at 1/N).  What RCCL reports (ncclCommCount, ncclCommCuDevice) and the PCI bus id of the HIP device are gathered
+        # over the communicator itself; any mismatch ends the run with a non-zero exit instead of a number.
+        n_seen, r_seen, dev_seen = eng.comm_info()
+        devs = allgather_scalar(float(dev_seen if dev_seen >= 0 else device))
+        ranks_seen = allgather_scalar(float(n_seen))
+        problems = []
+        if n_seen != world:
+            problems.append("the collective library reports %d ranks, the launcher started %d" % (n_seen, world))
+        if r_seen >= 0 and r_seen != rank:
+            problems.append("rank %d is rank %d of the communicator" % (rank, r_seen))
+        share = os.environ.get("RGCN_BENCH_SHARE_GPU") == "1"      # tests: N ranks on ONE GPU over a stand-in collective
+        if not share and len(set(int(x) for x in devs)) != world:
+            problems.append("ranks share a device: devices by rank = %s" % [int(x) for x in devs])
+        if any(int(x) != world for x in ranks_seen):
+            problems.append("ranks disagree about the communicator's size: %s" % [int(x) for x in ranks_seen])
+        if problems:
+            sys.stderr.write("bench.py --gpus %d: multi-GPU self-check FAILED on rank %d: %s\n" % (world, rank, "; ".join(problems)))
+            sys.exit(3)
     tri_dev = eng.to_device(triples)
     tri_dev_b = eng.to_device(triples_b)
     dc_dev = eng.to_device(dcodes)
@@ -557,9 +582,21 @@ def measure(workload, args, rk, steps, warmup, full):
     out = None
     if rank == 0:
         dataset = {"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(workload[:4], "FB15k-237")
-        if graph_name.startswith(("synth:", "sample:")):
-            data = ("synthetic graph: %d unique triples, relation and endpoint-given-relation histograms of the real "
-                    "FB15k-237 valid+test triples (SURVEY 8d graph B; the train split is not shipped), " % E_g)
+        graph_spec = None
+        if graph_name.startswith("synth:"):
+            _, pool, n_graph = graph_name.split(":")
+            graph_spec = {"kind": "synthetic", "pool_fixture": pool, "edges": int(n_graph)}
+            data = ("synthetic graph: %d unique triples drawn from the relation and endpoint-given-relation histograms of the "
+                    "real %s triples in fixture '%s' (SURVEY 8d graph B; the train split is not shipped), "
+                    % (E_g, dataset, pool))
+        elif graph_name.startswith("sample:"):
+            _, pool, n_graph, n_pick = graph_name.split(":")
+            graph_spec = {"kind": "uniform sample of a synthetic graph", "pool_fixture": pool, "graph_edges": int(n_graph),
+                          "edges": int(n_pick), "since_round": 5}
+            data = ("a uniform %d-edge minibatch (seed 3) of a synthetic %s-edge graph drawn from the relation and "
+                    "endpoint-given-relation histograms of the real %s triples in fixture '%s' (since round 5; earlier rounds "
+                    "timed this workload on the fixture's own 10,000 triples: not comparable), "
+                    % (E_g, n_graph, dataset, pool))
         else:
             data = "real graph structure (fixture %s of tests/golden/graphs.npz, %d edges; SURVEY 8d), " % (graph_name, E_g)
         out = {
@@ -571,7 +608,8 @@ def measure(workload, args, rk, steps, warmup, full):
                      "f32 (dense contractions: fp32 operands split exactly into 3 bf16, %d of 9 partial products on the "
                      "bf16 matrix cores, fp32 accumulation; error vs float64 equal to the fp32 MFMA's)" % args.gemm_mode,
             "data": data + "reference-distribution random-init weights, synthetic upstream gradient",
-            "config": {"workload": workload, "entities": V, "relations": R, "dim": d, "layers": L,
+            "config": {"workload": workload, "graph": graph_spec or {"kind": "fixture", "name": graph_name},
+                       "entities": V, "relations": R, "dim": d, "layers": L,
                        "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
                        "norm_mode": "intended (1/deg of the edge's own row; SURVEY H1, DESIGN section 10)",
                        "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "

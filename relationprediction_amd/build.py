@@ -24,11 +24,11 @@ LIB = os.path.join(LIBDIR, "librgcn.so")
 # tools/ and the dense-contraction tests; the product library has none of them
 LIB_DEVTOOLS = os.path.join(LIBDIR, "librgcn_devtools.so")
 ARCH = "gfx950"
-SOURCES = ["rgcn_api.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_w8.hip", "block_msgs.hip", "block_rows.hip", "basis.hip",
+SOURCES = ["rgcn_api.hip", "rgcn_schedule.hip", "rgcn_devtools.hip", "graph_prep.hip", "csr_sort.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_w8.hip", "block_msgs.hip", "block_rows.hip", "basis.hip",
            "elementwise.hip", "decoder.hip", "optimizer.hip", "ranking.hip", "sampler.hip", "neighborhood.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(CSRC, "gemm_split.h"), os.path.join(ROOT, "include", "rgcn.h"),
+HEADERS = [os.path.join(CSRC, "rgcn_internal.h"), os.path.join(CSRC, "rgcn_api_internal.h"), os.path.join(CSRC, "gemm_split.h"), os.path.join(ROOT, "include", "rgcn.h"),
            os.path.join(ROOT, "include", "rgcn_devtools.h")]
-DEVTOOLS_SOURCES = ["rgcn_api.hip", "comm.hip", "decoder.hip", "gemm_bf16x3.hip", "gemm_bf16x3_w8.hip"]       # the translation units the flag changes (knob())
+DEVTOOLS_SOURCES = ["rgcn_api.hip", "rgcn_devtools.hip", "comm.hip", "decoder.hip", "gemm_bf16x3.hip", "gemm_bf16x3_w8.hip"]       # the translation units the flag changes (knob())
 # No packed-FP32 VALU instructions anywhere in the library: on gfx950 a v_pk_fma_f32 (and kin) issued
 # by a wave that shares a CU with waves issuing v_mfma_f32_32x32x16_bf16 returns wrong low halves
 # (reproducer: tools/mfma_corun.hip).  The encoder runs its HBM-bound kernels on side

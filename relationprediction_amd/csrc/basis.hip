@@ -440,8 +440,12 @@ double basis_units(rgcn_ctx* c) {
   if (c->prof_on && !c->capturing) {
     if (c->g.units_host < 0) {
       int32_t n[2] = {0, 0};
+      // (the unit lists come from the graph preparation: on the prefetch stream, or in line on the MAIN stream -- which is
+      // not c->stream when this accounting runs inside a side-stream scope.  One readback per graph, profile runs only: the
+      // step that contains it is perturbed, which is why bench.py profiles in a pass of its own.)
       if (c->pf_stream) (void)hipStreamSynchronize(c->pf_stream);
-      (void)hipStreamSynchronize(c->stream);
+      (void)hipStreamSynchronize(c->main_stream);
+      if (c->stream != c->main_stream) (void)hipStreamSynchronize(c->stream);
       if (hipMemcpy(&n[0], c->g.unit_ptr + c->V, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
           hipMemcpy(&n[1], c->g.unit_ptr + 2 * c->V + 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
         c->g.units_host = (int64_t)n[0] + n[1];

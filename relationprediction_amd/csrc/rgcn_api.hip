@@ -1,15 +1,12 @@
-// C ABI of librgcn.so (include/rgcn.h) and the per-layer orchestration of the encoder:
-//   forward  (MessageGcn.compute_vertex_embeddings, code/encoders/message_gcns/message_gcn.py:49-79)
-//   backward (tf.gradients(loss, weights), code/optimization/abstract.py:117-118; formulas SURVEY 8a a15)
+// C ABI of librgcn.so (include/rgcn.h): contexts, parameters, graphs, steps, capture, profile.  The per-layer orchestration
+// of the encoder (which kernel on which stream) lives in rgcn_schedule.hip, the stand-alone entry points of the devtools
+// build in rgcn_devtools.hip; rgcn_api_internal.h is what the three share.
 #include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <new>
 
-#include "rgcn_internal.h"
-#ifdef RGCN_DEVTOOLS
-#include "../../include/rgcn_devtools.h"
-#endif
+#include "rgcn_api_internal.h"
 
 namespace rgcn {
 
@@ -70,13 +67,23 @@ rgcn_status stream_join(rgcn_ctx* c, int k) {
 
 // Side streams 0 and 1 behind ONE wait of the main stream (side 0 waits for side 1 first): where both were forked in the
 // same layer, the second wait is a packet the main stream can do without.
-static rgcn_status stream_join_both(rgcn_ctx* c) {
+rgcn_status stream_join_both(rgcn_ctx* c) {
   if (c->stream != c->main_stream) return RGCN_OK;
   if (c->aux_dirty[0] && c->aux_dirty[1]) {
     RGCN_HIP(c, hipEventRecord(c->ev_join[1], c->aux[1]));
     RGCN_HIP(c, hipStreamWaitEvent(c->aux[0], c->ev_join[1], 0));
     c->aux_dirty[1] = false;
   }
+  RGCN_TRY(stream_join(c, 0));
+  return stream_join(c, 1);
+}
+
+// A backward pass driven layer by layer (phase API) and abandoned between layers 2 and 1 leaves layer 2's side kernels
+// unjoined (bwd_layer_partial defers their joins to layer 1).  They read D / dS / the activations and the graph's message
+// lists: whoever is about to rewrite any of those -- the next forward pass, the next backward pass, a graph build on the
+// main stream -- joins them first.  Nothing is queued (and nothing is paid) in the usual case, where every pass ended joined.
+rgcn_status join_abandoned_side_work(rgcn_ctx* c) {
+  if (c->stream != c->main_stream) return RGCN_OK;
   RGCN_TRY(stream_join(c, 0));
   return stream_join(c, 1);
 }
@@ -116,17 +123,6 @@ static rgcn_status profile_collect(rgcn_ctx* c) {
 }
 
 // ---------------------------------------------------------------- helpers
-template <class T>
-static rgcn_status dmalloc(rgcn_ctx* c, T** p, size_t n, bool zero = true) {
-  *p = nullptr;
-  hipError_t e = hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
-  if (e != hipSuccess) {
-    c->err = std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e);
-    return e == hipErrorOutOfMemory ? RGCN_ERR_NOMEM : RGCN_ERR_HIP;
-  }
-  if (zero) RGCN_HIP(c, hipMemsetAsync(*p, 0, (n ? n : 1) * sizeof(T), c->stream));
-  return RGCN_OK;
-}
 
 static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_list<int64_t> shape,
                       float* val, float* grad, int layout) {
@@ -151,7 +147,7 @@ static void add_param(rgcn_ctx* c, const std::string& name, std::initializer_lis
 // basis kind (B = 2: 1.64 against 1.72).  profiles/r04_*: splitk A/B.  The rule reads the model's
 // dimensions only, one figure for every form of the layer: the split decides the summation order of dW_self, and the forms
 // are held bitwise equal to each other.
-static int auto_split_k(int M, int N, int K, bool narrow = false) {
+int auto_split_k(int M, int N, int K, bool narrow) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   if (tiles >= 192) return 1;
   const int target = narrow ? 256 : 512;
@@ -208,13 +204,13 @@ static void invalidate_prefetch_of(rgcn_ctx* c, const void* dev, size_t bytes) {
   }
 }
 
-static rgcn_status to_host(rgcn_ctx* c, void* host, const void* dev, size_t bytes) {
+rgcn_status to_host(rgcn_ctx* c, void* host, const void* dev, size_t bytes) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
   RGCN_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));
   return RGCN_OK;
 }
-static rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes) {
+rgcn_status to_dev(rgcn_ctx* c, void* dev, const void* host, size_t bytes) {
   if (c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "host transfers are not allowed while a hipGraph is being captured");
   RGCN_HIP(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
   RGCN_HIP(c, hipStreamSynchronize(c->stream));   // host memory is borrowed for the call only
@@ -376,9 +372,9 @@ static rgcn_status create_impl(rgcn_ctx* c) {
     RGCN_HIP(c, acquire_stream(f.device, c->pf_priority, &c->pf_stream));
     c->aux[2] = c->pf_stream;
     for (int k = 0; k < kAuxStreams; ++k)
-      RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], order_event_flags(c)));
+      RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], order_event_flags(c, true)));
   }
-  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, order_event_flags(c)));
+  RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, order_event_flags(c, true)));
   RGCN_HIP(c, hipEventCreateWithFlags(&c->ev_step_begin, order_event_flags(c)));
   // Block kind: the destination-major banded single pass (block_rows.hip; rgcn_set_fusion 1, the default) -- no message
   // buffer, weights through L2: 39-41 us forward / 46-48 backward per layer against 57 / 75 for the two-kernel form
@@ -525,475 +521,11 @@ static rgcn_status param_download(rgcn_ctx* c, const Param& p, const float* src,
   return to_host(c, host, c->stage, sizeof(float) * p.count);
 }
 
-// ---------------------------------------------------------------- forward
-static rgcn_status fwd_begin(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks_host) {
-  if (!c->g.ready) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_forward before rgcn_set_graph");
-  // (a backward pass that was driven layer by layer and abandoned between layers 2 and 1 left its side kernels unjoined:
-  // they read the activations this pass overwrites.  Nothing is queued in the usual case, where every pass ended joined.)
-  if (c->stream == c->main_stream) {
-    RGCN_TRY(stream_join(c, 0));
-    RGCN_TRY(stream_join(c, 1));
-  }
-  c->fwd_done = false;
-  c->frag_fresh = false;
-  c->wtile_fresh = false;
-  c->fwd_train = train ? 1 : 0;
-  c->seed = seed;
-  c->explicit_masks = false;
-  if (train && masks_host) {
-    const size_t n = (size_t)c->L * c->V * c->d;
-    if (!c->masks) RGCN_TRY(dmalloc(c, &c->masks, n, false));
-    RGCN_TRY(to_dev(c, c->masks, masks_host, n));
-    c->explicit_masks = true;
-  }
-  return input_forward(c);
-}
-
-// The all-gather of the rows finished last runs on side stream 1; whoever needs ALL rows (message kernels, the
-// decoder, the column sums) makes its stream wait here, whoever needs the rank's own rows only (self-loop GEMMs) does not.
-static rgcn_status wait_gather(rgcn_ctx* c) {
-  if (c->gather_pending) {
-    RGCN_HIP(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));
-    if (c->stream == c->main_stream) c->gather_pending = false;
-  }
-  return RGCN_OK;
-}
-// all-gather the [V_pad,d] buffer whose own rows this rank just finished, beside whatever the main stream does next
-static rgcn_status gather_rows(rgcn_ctx* c, float* buf) {
-  StreamScope side(c, 1);
-  RGCN_TRY(comm_all_gather(c, buf, (int64_t)c->shard_rows * c->d));
-  if (side.active) {
-    RGCN_HIP(c, hipEventRecord(c->ev_gather, c->aux[1]));
-    c->gather_pending = true;
-  }
-  return RGCN_OK;
-}
-
-// The block layer destination-major in ONE pass over the incidence CSR, one column band per XCD, weights through L2
-// (block_rows.hip): block kind, any world.  Otherwise (rgcn_set_fusion 0, or more blocks than the kernel's lane groups
-// cover) the two-kernel form: relation-major message kernel + k_combine.
-static bool rows_layer(const rgcn_ctx* c) { return c->fuse == 1 && block_rows_available(c); }
-
-// Fragment tables of the weights that are the B operand of a contraction (W_self of every layer in both orientations, the
-// basis tensors), rebuilt -- all of them, one launch -- when the weights changed (set_param, Adam) and once inside every
-// captured step, whose replays follow weights the host does not see.  Nothing to do when the dense contractions run on
-// the fp32 MFMA (no split, nothing to pre-split).
-static rgcn_status refresh_weight_fragments(rgcn_ctx* c) {
-  if (c->gemm_mode == 0) return RGCN_OK;
-  if (c->capturing ? c->frag_fresh : c->frag_version == c->weights_version) return RGCN_OK;
-  std::vector<PresplitJob> jobs;
-  const int d = c->d, Bd = c->B * c->d;
-  for (int l = 1; l <= c->L; ++l) {
-    LayerBufs& lb = c->layers[l];
-    if (!lb.wself_nn || !lb.wself_nt) continue;
-    jobs.push_back(PresplitJob{lb.wself, lb.wself_nn, d, d, d, 0});      // H . W_self:      B (k, n) = W[k][n]
-    jobs.push_back(PresplitJob{lb.wself, lb.wself_nt, d, d, d, 1});      // dS . W_self^T:   B (k, n) = W[n][k]
-    if (c->kind == RGCN_KIND_BASIS && lb.wrel_nn && lb.wrel_nt)
-      for (int g = 0; g < 2; ++g) {
-        const float* W = lb.wrel + (size_t)g * Bd * d;                   // W'_dir [B.d, d]
-        jobs.push_back(PresplitJob{W, static_cast<char*>(lb.wrel_nn) + 16 * g * gemm_bfrag_words(Bd, d), d, Bd, d, 0});
-        jobs.push_back(PresplitJob{W, static_cast<char*>(lb.wrel_nt) + 16 * g * gemm_bfrag_words(d, Bd), d, d, Bd, 1});
-      }
-  }
-  if (!jobs.empty()) RGCN_TRY(gemm_presplit_b(c, jobs.data(), (int)jobs.size()));
-  c->frag_fresh = true;
-  c->frag_version = c->capturing ? ~0ull : c->weights_version;
-  return RGCN_OK;
-}
-// the self-loop products: one group, W_self as the pre-split B operand (forward: [k][n]; dH: used transposed, [n][k])
-static rgcn_status self_loop_batch(rgcn_ctx* c, int l, bool transposed, GemmBatch* b) {
-  *b = GemmBatch();
-  RGCN_TRY(refresh_weight_fragments(c));
-  if (c->gemm_mode != 0) b->bfrag = transposed ? c->layers[l].wself_nt : c->layers[l].wself_nn;
-  b->wide = transposed ? 0 : 1;
-  return RGCN_OK;
-}
-
-// Basis kind: the two direction groups of a batched GEMM over the (row, direction) units of the current graph; the
-// group's extent (rows of A / C, or the depth of dW') is the direction's unit count, read on the device.
-static GemmBatch basis_batch(const rgcn_ctx* c, size_t strideA, size_t strideB, size_t strideC, bool limit_on_k) {
-  GemmBatch b;
-  b.groups = 2;
-  b.strideA = strideA; b.strideB = strideB; b.strideC = strideC;
-  b.limit = c->g.unit_ptr + c->V;
-  b.limit_stride = c->V + 1;
-  b.limit_on_k = limit_on_k ? 1 : 0;
-  return b;
-}
-static double basis_unit_share(rgcn_ctx* c) { return basis_units(c) / (2.0 * c->V); }
-
-static rgcn_status fwd_layer_partial(rgcn_ctx* c, int l) {
-  if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
-  const float* Hin = c->H[l - 1];
-  const int d = c->d, V = c->V;
-  const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
-  float* dst = c->world > 1 ? c->exch : c->H[l];
-  const double Mmsg = 2.0 * c->g.E / c->world;
-  GemmBatch sb;
-  RGCN_TRY(self_loop_batch(c, l, false, &sb));
-  if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
-    // S = H . W_self, then ONE kernel: H' = relu(dropout(S) + sum over the row's messages of n W_r H[src]) straight from
-    // the incidence CSR (no message buffer)
-    // (sharded run: the self-loop GEMM covers this rank's row shard, the kernel walks the rank's own messages and writes
-    // the PARTIAL pre-activations -- the self-loop term inside the shard only, no relu -- for the reduce-scatter that
-    // follows)
-    RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d, c->layers[l].wself, d,
-                      c->self_buf + (size_t)lo * d, d, 1, &sb));
-    RGCN_TRY(wait_gather(c));
-    CombineArgs a;
-    a.add = nullptr; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
-    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.gate = nullptr; a.V = V; a.d = d;
-    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
-    a.row_lo = lo; a.row_hi = hi;
-    a.drop = make_drop(c, l, true);
-    a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(block_rows(c, "block_rows_fwd", l, false, Hin, a));
-  } else if (c->kind == RGCN_KIND_BLOCK) {
-    // Two-kernel form.  The relational messages (HBM-bound) run beside the self-loop GEMM.  A stream that blocks on
-    // another stream's event resumes ~10 us after the event fires, so the chain that continues (the combine) stays on
-    // the stream of the kernel that finishes LAST: the messages on the main stream, the (shorter) GEMM forked.
-    {   // self-loop: S = H . W_self  (rows of this rank's shard)
-      StreamScope side(c, 0);
-      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1, &sb));
-    }
-    RGCN_TRY(wait_gather(c));
-    RGCN_TRY(block_msg_forward(c, l, Hin, c->msgbuf));
-    RGCN_TRY(stream_join(c, 0));
-    CombineArgs a;
-    a.add = nullptr;
-    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
-    a.row_ptr = c->g.row_ptr; a.long_rows = c->g.long_rows; a.nlong = c->g.nlong; a.gate = nullptr; a.V = V; a.d = d;
-    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
-    a.row_lo = lo; a.row_hi = hi;
-    a.drop = make_drop(c, l, true);
-    a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + Mmsg) + 4.0 * V));
-  } else {
-    // aggregate first, per (row, direction) unit: Zc[(v,dir),b,:] = sum n C[rel,b] H[src];
-    // pre[v] = dropout(H.W_self)[v] + sum_dir Zc[(v,dir)] . W'_dir  -- two groups of one batched GEMM over the units
-    const int Bd = c->B * d;
-    // the self-loop GEMM needs the layer input only: it runs on side stream 1 beside the aggregation (HBM-bound) and
-    // then beside the basis GEMM
-    {
-      StreamScope side(c, 1);
-      RGCN_TRY(gemm_f32(c, "gemm_self_fwd", true, false, hi - lo, d, d, Hin + (size_t)lo * d, d,
-                        c->layers[l].wself, d, c->self_buf + (size_t)lo * d, d, 1, &sb));
-    }
-    RGCN_TRY(wait_gather(c));
-    RGCN_TRY(basis_aggregate_forward(c, l, Hin, c->zsave[l]));
-    GemmBatch gb = basis_batch(c, (size_t)V * Bd, (size_t)Bd * d, (size_t)V * d, false);
-    RGCN_TRY(refresh_weight_fragments(c));
-    if (c->gemm_mode != 0) gb.bfrag = c->layers[l].wrel_nn;
-    gb.strideBfrag = gemm_bfrag_words(Bd, d);
-    gb.wide = 1;
-    RGCN_TRY(gemm_f32(c, "gemm_basis_fwd", true, false, V, d, Bd, c->zsave[l], Bd, c->layers[l].wrel, d,
-                      c->aggbuf, d, 1, &gb, basis_unit_share(c)));
-    RGCN_TRY(stream_join(c, 1));
-    CombineArgs a;
-    a.add = nullptr;
-    a.add_units = c->aggbuf; a.unit_ptr = c->g.unit_ptr;
-    a.out = dst; a.out2 = nullptr; a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr;
-    a.long_rows = nullptr; a.nlong = nullptr; a.gate = nullptr; a.V = V; a.d = d;
-    a.relu = (c->world == 1 && l < c->L) ? 1 : 0;
-    a.row_lo = lo; a.row_hi = hi;
-    a.drop = make_drop(c, l, true);
-    a.drop2 = make_drop(c, l, false);
-    RGCN_TRY(combine(c, "combine_fwd", a, 4.0 * d * (2.0 * V + 2.0 * V * basis_unit_share(c)) + 8.0 * V));
-  }
-  return RGCN_OK;
-}
-
-static rgcn_status fwd_layer_finish(rgcn_ctx* c, int l) {
-  if (l < 1 || l > c->L) RGCN_FAIL(c, RGCN_ERR_INVALID, "layer out of range");
-  if (c->world > 1)
-    RGCN_TRY(relu_copy(c, c->exch, c->H[l], (int64_t)c->V * c->d, l < c->L ? 1 : 0));
-  if (l == c->L) c->fwd_done = true;
-  return RGCN_OK;
-}
-
-// ---------------------------------------------------------------- backward
-// ds_ready: dcodes * dropout of the top layer, already written by the producer of dcodes (the device decoder does,
-// inside a train step): the scale-and-copy pass over [V,d] is skipped
-static rgcn_status bwd_begin(rgcn_ctx* c, const float* dcodes_dev, const float* ds_ready = nullptr) {
-  if (!c->fwd_done) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward needs a completed rgcn_forward on the current graph");
-  if (!dcodes_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "dcodes is NULL");
-  c->bwd_layer = c->L;
-  c->bwd_D = dcodes_dev;
-  DropSpec ds = make_drop(c, c->L, true);
-  if (ds.mode != DROP_NONE && ds_ready != nullptr) {
-    c->bwd_dS = ds_ready;
-  } else if (ds.mode != DROP_NONE) {
-    RGCN_TRY(scale_dropout(c, dcodes_dev, c->dsbuf[c->L & 1], ds));
-    c->bwd_dS = c->dsbuf[c->L & 1];
-  } else {
-    c->bwd_dS = dcodes_dev;
-  }
-  return RGCN_OK;
-}
-
-static rgcn_status bwd_layer_partial(rgcn_ctx* c, int l) {
-  if (l != c->bwd_layer || l < 1) RGCN_FAIL(c, RGCN_ERR_STATE, "backward layers must run L..1 in order");
-  const float* Hin = c->H[l - 1];
-  const int d = c->d, V = c->V;
-  const int lo = c->world > 1 ? c->row_lo : 0, hi = c->world > 1 ? c->row_hi : V;
-  const int rows = hi - lo;
-  LayerBufs& lb = c->layers[l];
-  const double Mmsg = 2.0 * c->g.E / c->world;
-  const bool narrow_dw = c->kind == RGCN_KIND_BASIS || rows >= 32768;       // (see auto_split_k)
-
-  // epilogue shared by both kinds: (self-loop gradient + relational gradient) -> relu' -> next D / dS
-  CombineArgs a;
-  a.add = nullptr;
-  a.base = c->self_buf; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
-  a.V = V; a.d = d; a.relu = 0; a.row_lo = lo; a.row_hi = hi;
-  a.drop = make_drop(c, l, false);
-  if (c->world == 1) {
-    a.out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
-    a.colsum = (l - 1 == 0) ? 1 : 0;       // db_emb = the column sums of dL/dH0 * relu'(H0): partials from the kernel that writes it
-    a.drop2 = make_drop(c, l - 1, l - 1 >= 1);
-    a.out2 = a.drop2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
-    a.gate = Hin;
-  } else {
-    a.out = c->exch; a.out2 = nullptr; a.gate = nullptr; a.drop2 = make_drop(c, l, false);
-  }
-
-  if (c->dw_pending) {       // the previous layer's weight-gradient kernel reads the D buffer this layer may overwrite
-    RGCN_TRY(stream_join(c, 0));
-    c->dw_pending = false;
-  }
-  // the three dense / relation-weight pieces every block schedule below is made of
-  auto self_dw = [&]() {      // dW_self = H_in^T . dS   (split-K)
-    return gemm_f32(c, "gemm_self_dw", false, false, d, d, rows, Hin + (size_t)lo * d, d, c->bwd_dS + (size_t)lo * d, d,
-                    lb.gwself, d, auto_split_k(d, d, rows, narrow_dw));
-  };
-  GemmBatch sbt;
-  RGCN_TRY(self_loop_batch(c, l, true, &sbt));
-  auto self_dh = [&]() {      // G = dS . W_self^T
-    return gemm_f32(c, "gemm_self_dh", true, true, rows, d, d, c->bwd_dS + (size_t)lo * d, d, lb.wself, d,
-                    c->self_buf + (size_t)lo * d, d, 1, &sbt);
-  };
-  bool defer_joins = false;
-  if (c->kind == RGCN_KIND_BLOCK && rows_layer(c)) {
-    // Row gradients: the single-pass kernel behind G = dS . W_self^T.  Relation-weight gradients (dW_r = sum n g (x) x,
-    // relation-major, two row gathers per message): k_block_msg_bwd<dW only> + its slab reduce.  ONE schedule per
-    // situation, each the measured best of round 4's A/Bs (profiles/r04_rowmajor_spmm_ab.md, r04_block_forms_ab.txt):
-    //   minibatch scale, one GPU, side streams on:  dW_self forked BEFORE dH is launched (MFMA beside MFMA: the second
-    //       GEMM fills the slots the first leaves idle, 456 workgroups on 512, and its tail), the relation-weight kernels
-    //       forked BEHIND dH, beside the row-gradient kernel (two gather kernels share the chip better than either does
-    //       with a GEMM), joined at the end of the layer: 0.553-0.556 ms per step against 0.597-0.599 as a chain (round 5,
-    //       same box: dW_self forked BEHIND dH instead, beside the row-gradient kernel: 0.567-0.578 against 0.541-0.547);
-    //   the same inside a capture (a captured step is a chain, rgcn_capture_begin) or with the side streams off: the
-    //       chain, with the one fork a replayed graph gains from -- the slab reduce + dW_self beside dH;
-    //   full-graph scale or a sharded run: the relation-weight kernels on side stream 0 from the start of the layer
-    //       (at 272,115 edges they are five GEMMs long; a sharded run's all-gather rides on side stream 1), joined
-    //       before the next layer overwrites D.
-    const bool minibatch = c->world == 1 && c->g.E <= 65536;
-    if (minibatch && c->use_aux) {
-      {
-        StreamScope side(c, 1);
-        RGCN_TRY(self_dw());
-      }
-      RGCN_TRY(self_dh());
-      {
-        StreamScope side(c, 0);
-        RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-        RGCN_TRY(block_dw_reduce(c, l));
-      }
-      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
-      // Layer 2's side kernels read H_1, D_2 and dS_2 and write their own slabs and gradients.  Layer 1, next, overwrites
-      // none of those (its rows go to g_emb) and queues its side kernels behind them in stream order: its joins cover
-      // both layers, and the main stream saves two waits between the layers.
-      defer_joins = l == 2;
-      if (!defer_joins) RGCN_TRY(stream_join_both(c));
-    } else if (minibatch) {
-      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-      {
-        StreamScope side(c, 1, /*in_capture=*/true);
-        RGCN_TRY(block_dw_reduce(c, l));
-        RGCN_TRY(self_dw());
-      }
-      RGCN_TRY(self_dh());
-      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
-    } else {
-      {
-        StreamScope side(c, 0);
-        RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
-        RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, nullptr));
-        RGCN_TRY(block_dw_reduce(c, l));
-        c->dw_pending = side.active;
-      }
-      {
-        StreamScope side(c, 1);
-        RGCN_TRY(self_dw());
-      }
-      RGCN_TRY(self_dh());
-      RGCN_TRY(wait_gather(c));
-      RGCN_TRY(block_rows(c, "block_rows_bwd", l, true, c->bwd_D, a));
-    }
-  } else if (c->kind == RGCN_KIND_BLOCK) {
-    {   // two-kernel form: the relational gradient kernels (HBM-bound) on a side stream beside the self-loop GEMMs
-      StreamScope side(c, 0);
-      RGCN_TRY(wait_gather(c));          // D_l of every row (sharded run: gathered beside the self-loop GEMMs)
-      RGCN_TRY(block_msg_backward(c, l, Hin, c->bwd_D, c->msgbuf));
-      // the combine below needs only the message rows: mark the join point here, then let the
-      // per-relation dW reduction trail behind on the side stream
-      if (side.active) RGCN_HIP(c, hipEventRecord(c->ev_join[0], c->aux[0]));
-      RGCN_TRY(block_dw_reduce(c, l));
-    }
-    RGCN_TRY(self_dh());
-    {   // dW_self on side stream 1, queued behind the dH GEMM
-      StreamScope side(c, 1);
-      RGCN_TRY(self_dw());
-    }
-    if (c->use_aux) RGCN_HIP(c, hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0));
-    a.msg = c->g.E > 0 ? c->msgbuf : nullptr;
-    a.row_ptr = c->g.row_ptr;
-    a.long_rows = c->g.long_rows;
-    a.nlong = c->g.nlong;
-    RGCN_TRY(combine(c, "combine_bwd", a, 4.0 * d * ((a.out2 ? 4.0 : 3.0) * V + Mmsg) + 4.0 * V));
-  } else {
-    const int Bd = c->B * d;
-    // The upstream rows of the units, compacted like Zc (the row operand of dZ, the depth operand of dW')
-    RGCN_TRY(wait_gather(c));            // D_l of every row
-    RGCN_TRY(basis_gather_units(c, c->bwd_D, c->aggbuf));
-    // The four dense contractions of the layer depend on D_l / dS_l only.  Two of them -- the weight gradients dW_self =
-    // H^T.dS and dW'_dir = Zc_dir^T.D[units], needed at the end of the pass -- go to side stream 1, the two whose
-    // products the gather kernels below consume (dH's self-loop part, dZ) stay on the main stream: the pairs fill each
-    // other's idle CU slots and tails.
-    {
-      StreamScope side(c, 1);
-      RGCN_TRY(self_dw());
-      // dW'_dir = Zc_dir^T . Dc_dir   ([B.d, units] x [units, d], split over the units; two groups)
-      const GemmBatch gk = basis_batch(c, (size_t)V * Bd, (size_t)V * d, (size_t)Bd * d, true);
-      RGCN_TRY(gemm_f32(c, "gemm_basis_dw", false, false, Bd, d, V, c->zsave[l], Bd, c->aggbuf, d, lb.grel, d,
-                        auto_split_k(2 * Bd, d, V), &gk, basis_unit_share(c)));
-    }
-    RGCN_TRY(self_dh());
-    // dZc_dir = Dc_dir . W'_dir^T   ([units, d] x [d, B.d], two groups)
-    GemmBatch gm = basis_batch(c, (size_t)V * d, (size_t)Bd * d, (size_t)V * Bd, false);
-    RGCN_TRY(refresh_weight_fragments(c));
-    if (c->gemm_mode != 0) gm.bfrag = lb.wrel_nt;
-    gm.strideBfrag = gemm_bfrag_words(d, Bd);
-    RGCN_TRY(gemm_f32(c, "gemm_basis_dz", true, true, V, Bd, d, c->aggbuf, d, lb.wrel, d, c->msgbuf2, Bd, 1, &gm,
-                      basis_unit_share(c)));
-    RGCN_TRY(basis_dcoef(c, l, Hin, c->msgbuf2));
-    RGCN_TRY(basis_backward_gather(c, l, c->msgbuf2, a, true));
-  }
-  // the dW_self GEMM must be done before the next layer overwrites its dS operand / the caller
-  // all-reduces gwself
-  if (!defer_joins) RGCN_TRY(stream_join(c, 1));
-  return RGCN_OK;
-}
-
-static rgcn_status bwd_layer_finish(rgcn_ctx* c, int l) {
-  if (l != c->bwd_layer || l < 1) RGCN_FAIL(c, RGCN_ERR_STATE, "backward layers must run L..1 in order");
-  float* out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
-  DropSpec d2 = make_drop(c, l - 1, l - 1 >= 1);
-  float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
-  if (c->world > 1) {
-    CombineArgs a;
-    a.add = nullptr;
-    a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
-    a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = 0; a.row_hi = c->V;
-    a.drop = make_drop(c, l, false);
-    a.drop2 = d2;
-    RGCN_TRY(combine(c, "combine_bwd_finish", a, 4.0 * c->d * (out2 ? 4.0 : 3.0) * c->V));
-  }
-  c->bwd_D = out;
-  c->bwd_dS = out2 ? out2 : out;
-  c->bwd_layer = l - 1;
-  return RGCN_OK;
-}
-
-static rgcn_status bwd_end(rgcn_ctx* c) {
-  if (c->bwd_layer != 0) RGCN_FAIL(c, RGCN_ERR_STATE, "rgcn_backward_end before all layers ran");
-  // AffineTransform: dW_emb = dH0 * (H0 > 0) is already in g_emb; db_emb = column sums
-  // (single-pass block layer on one GPU: the bottom layer's row-gradient kernel left the column sums of its rows as partials)
-  if (c->colsum_parts > 0) RGCN_TRY(column_sum_finish(c, c->gb_emb, c->colsum_parts, c->d));
-  else RGCN_TRY(column_sum(c, c->g_emb, c->gb_emb, c->V, c->d));
-  c->colsum_parts = 0;
-  c->dw_pending = false;
-  return stream_join(c, 0);   // trailing per-relation dW reductions
-}
-
-// Sharded run with a communicator, forward exchange of layer l: the partial pre-activations are reduce-scattered,
-// this rank applies the relu to ITS rows only, and the finished rows are all-gathered on side stream 1 while the main
-// stream goes on (the next self-loop GEMM needs the rank's own rows, nothing else).
-static rgcn_status fwd_exchange(rgcn_ctx* c, int l) {
-  const int64_t chunk = (int64_t)c->shard_rows * c->d;
-  RGCN_TRY(comm_reduce_scatter(c, c->exch, chunk));
-  const size_t off = (size_t)c->rank * chunk;
-  RGCN_TRY(relu_copy(c, c->exch + off, c->H[l] + off, chunk, l < c->L ? 1 : 0));
-  RGCN_TRY(gather_rows(c, c->H[l]));
-  if (l == c->L) {
-    RGCN_TRY(wait_gather(c));          // the codes: every row, on the main stream
-    c->fwd_done = true;
-  }
-  return RGCN_OK;
-}
-
-// Backward exchange of layer l: partial dH reduce-scattered, (relu', dropout) on the rank's rows, D_{l-1} gathered.
-static rgcn_status bwd_exchange(rgcn_ctx* c, int l) {
-  const int64_t chunk = (int64_t)c->shard_rows * c->d;
-  RGCN_TRY(comm_reduce_scatter(c, c->exch, chunk));
-  float* out = (l - 1 == 0) ? c->g_emb : c->dbuf[(l - 1) & 1];
-  DropSpec d2 = make_drop(c, l - 1, l - 1 >= 1);
-  float* out2 = d2.mode != DROP_NONE ? c->dsbuf[(l - 1) & 1] : nullptr;
-  CombineArgs a;
-  a.add = nullptr;
-  a.out = out; a.out2 = out2; a.base = c->exch; a.msg = nullptr; a.row_ptr = nullptr; a.long_rows = nullptr; a.nlong = nullptr;
-  a.gate = c->H[l - 1]; a.V = c->V; a.d = c->d; a.relu = 0; a.row_lo = c->row_lo; a.row_hi = c->row_hi;
-  a.v_begin = c->row_lo; a.v_count = c->row_hi - c->row_lo;
-  a.drop = make_drop(c, l, false);
-  a.drop2 = d2;
-  if (a.v_count > 0) RGCN_TRY(combine(c, "combine_bwd_finish", a, 4.0 * c->d * (out2 ? 4.0 : 3.0) * a.v_count));
-  RGCN_TRY(gather_rows(c, out));
-  c->bwd_D = out;
-  c->bwd_dS = out2 ? out2 : out;      // own rows only: all the row-sharded self-loop GEMMs read
-  c->bwd_layer = l - 1;
-  return RGCN_OK;
-}
-
-static rgcn_status forward_all(rgcn_ctx* c, int train, uint64_t seed, const uint8_t* masks) {
-  if (c->world > 1 && !c->comm)
-    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
-  RGCN_TRY(fwd_begin(c, train, seed, masks));
-  for (int l = 1; l <= c->L; ++l) {
-    RGCN_TRY(fwd_layer_partial(c, l));
-    if (c->world > 1) RGCN_TRY(fwd_exchange(c, l));
-    else RGCN_TRY(fwd_layer_finish(c, l));
-  }
-  return RGCN_OK;
-}
-
-static rgcn_status backward_all(rgcn_ctx* c, const float* dcodes_dev, const float* ds_ready = nullptr) {
-  if (c->world > 1 && !c->comm)
-    RGCN_FAIL(c, RGCN_ERR_STATE, "world > 1: call rgcn_comm_init first (or drive the phase API yourself)");
-  RGCN_TRY(bwd_begin(c, dcodes_dev, ds_ready));
-  for (int l = c->L; l >= 1; --l) {
-    RGCN_TRY(bwd_layer_partial(c, l));
-    if (c->world > 1) RGCN_TRY(bwd_exchange(c, l));
-    else RGCN_TRY(bwd_layer_finish(c, l));
-  }
-  if (c->world > 1) {
-    RGCN_TRY(wait_gather(c));          // dW_emb of every row (optimizer, column sums)
-    // W_self (and basis W') gradients of all layers: partial sums over the row / relation shards, one collective
-    RGCN_TRY(comm_allreduce(c, c->repl_grads, (int64_t)c->repl_grads_floats));
-  }
-  return bwd_end(c);
-}
-
 }  // namespace rgcn
 
 using namespace rgcn;
 
 // ================================================================= C ABI
-#define RGCN_NEED(c)                \
-  do {                              \
-    if (!(c)) return RGCN_ERR_INVALID; \
-    (void)hipSetDevice((c)->cfg.device); \
-  } while (0)
 
 extern "C" {
 
@@ -1083,6 +615,7 @@ rgcn_status rgcn_set_graph(rgcn_ctx* c, const int32_t* tri, int64_t E) {
     if (s < 0 || s >= c->V || o < 0 || o >= c->V || r < 0 || r >= c->R)
       RGCN_FAIL(c, RGCN_ERR_INVALID, "graph_edges row " + std::to_string(e) + " has an id out of range");
   }
+  RGCN_TRY(join_abandoned_side_work(c));      // (they read the message lists the build rewrites)
   if (E > 0) RGCN_TRY(to_dev(c, c->g.triples, tri, sizeof(int32_t) * 3 * (size_t)E));
   return graph_build(c, c->g.triples, E);
 }
@@ -1091,6 +624,7 @@ rgcn_status rgcn_set_graph_device(rgcn_ctx* c, const int32_t* tri_dev, int64_t E
   RGCN_NEED(c);
   if (E < 0 || E > c->cfg.max_edges) RGCN_FAIL(c, RGCN_ERR_INVALID, "num_edges outside [0, max_edges]");
   if (E > 0 && !tri_dev) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL triples");
+  RGCN_TRY(join_abandoned_side_work(c));
   return graph_build(c, tri_dev, E);
 }
 
@@ -1143,6 +677,7 @@ rgcn_status rgcn_backward(rgcn_ctx* c, const float* dcodes_host, int64_t count) 
 // an encoder step outside a capture has no such fork and saves the main stream the packet.
 static rgcn_status step_begin(rgcn_ctx* c, const int32_t* tri_dev, int64_t E, bool fork_point, int64_t keep = -1,
                               uint64_t eseed = 0) {
+  RGCN_TRY(join_abandoned_side_work(c));
   if (fork_point || c->capturing) RGCN_HIP(c, hipEventRecord(c->ev_step_begin, c->main_stream));
   c->step_begin_in_capture = c->capturing;
   if (c->g_alt.pf_valid && c->g_alt.pf_tri == tri_dev && c->g_alt.pf_E == E && c->g_alt.pf_keep == keep &&
@@ -1474,12 +1009,18 @@ rgcn_status rgcn_capture_begin(rgcn_ctx* c) {
   c->cap_pf_forked = false;
   RGCN_HIP(c, hipStreamBeginCapture(c->main_stream, hipStreamCaptureModeRelaxed));
   c->capturing = true;
+  // whatever the capture does first, the weights' derived tables (MFMA fragments, band tiles) are rebuilt INSIDE it: a
+  // replay follows weights the host does not see, tables built before the capture would be baked in stale
+  c->frag_fresh = false;
+  c->wtile_fresh = false;
   // A captured step is recorded as ONE chain on the main stream (only the prefetch of the next graph forks off):
   // the replayed graph pays more than streams do for every cross-stream edge (measured, profiles/r02_hipgraph_ab.log:
   // 0.687 ms per step with the side streams captured, 0.634-0.640 as a chain, 0.614-0.631 stream-launched), and
   // the side streams buy the stream-launched step under 3 %.
+  // (devtools knob RGCN_CAPTURE_STREAMS=1 records the stream-launched step's own fork / join DAG instead: the A/B of
+  // every round, tools/gpu_r6_capture_ab.sh)
   c->use_aux_before_capture = c->use_aux;
-  c->use_aux = false;
+  if (knob("RGCN_CAPTURE_STREAMS", 0) != 1) c->use_aux = false;
   hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, c->main_stream, c->replay_counter);
   return RGCN_OK;
 }
@@ -1489,6 +1030,12 @@ rgcn_status rgcn_capture_end(rgcn_ctx* c, int32_t* graph_id) {
   if (!c->capturing) RGCN_FAIL(c, RGCN_ERR_STATE, "no capture is running");
   if (!graph_id) RGCN_FAIL(c, RGCN_ERR_INVALID, "NULL graph_id");
   hipError_t e = hipSuccess;
+  for (int k = 0; k < kAuxStreams; ++k)        // (side streams forked inside the capture rejoin the origin stream)
+    if (c->use_aux && c->aux[k] && c->aux_dirty[k]) {
+      c->aux_dirty[k] = false;
+      if (e == hipSuccess) e = hipEventRecord(c->ev_join[k], c->aux[k]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->main_stream, c->ev_join[k], 0);
+    }
   if (c->cap_pf_forked) {                      // the prefetch stream must rejoin the origin stream
     e = hipEventRecord(c->ev_join[0], c->pf_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->main_stream, c->ev_join[0], 0);
@@ -1496,6 +1043,8 @@ rgcn_status rgcn_capture_end(rgcn_ctx* c, int32_t* graph_id) {
   hipGraph_t graph = nullptr;
   const hipError_t e2 = hipStreamEndCapture(c->main_stream, &graph);
   c->capturing = false;
+  c->frag_fresh = false;
+  c->wtile_fresh = false;
   c->use_aux = c->use_aux_before_capture;
   // events last recorded inside the capture are unusable outside it: give them a fresh, ordinary record
   (void)hipEventRecord(c->ev_fork, c->main_stream);
@@ -1776,140 +1325,5 @@ rgcn_status rgcn_profile_get_compulsory(rgcn_ctx* c, int32_t i, double* compulso
   return RGCN_OK;
 }
 
-#ifdef RGCN_DEVTOOLS
-namespace {
-// the XCD every workgroup of a plain 1-D launch lands on (HW_REG_XCC_ID, bits 3:0)
-__global__ void k_xcd_of_block(int32_t* out) {
-  uint32_t id;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(id & 0xf);
-}
-}  // namespace
-
-rgcn_status rgcn_debug_xcd_map(rgcn_ctx* c, int32_t n_blocks, int32_t* out_host) {
-  RGCN_NEED(c);
-  if (n_blocks <= 0 || !out_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
-  int32_t* dev = nullptr;
-  RGCN_TRY(dmalloc(c, &dev, (size_t)n_blocks));
-  hipLaunchKernelGGL(k_xcd_of_block, dim3((unsigned)n_blocks), dim3(256), 0, c->stream, dev);
-  rgcn_status s = hipGetLastError() == hipSuccess ? RGCN_OK : RGCN_ERR_HIP;
-  if (s == RGCN_OK) s = to_host(c, out_host, dev, sizeof(int32_t) * (size_t)n_blocks);
-  (void)hipFree(dev);
-  return s;
-}
-
-rgcn_status rgcn_debug_gemm(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
-                            int32_t split_k, const float* a_host, const float* b_host, float* c_host) {
-  RGCN_NEED(c);
-  if (M <= 0 || N <= 0 || K <= 0 || !a_host || !b_host || !c_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
-  if (ta && tb) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "TT form not instantiated");
-  float *A = nullptr, *B = nullptr, *C = nullptr;
-  rgcn_status s = RGCN_OK;
-  do {
-    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
-    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
-    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
-    int sk = split_k > 0 ? split_k : auto_split_k(M, N, K);
-    if ((size_t)sk * M * N > c->slab_floats) sk = 1;
-    // trans_a: A given as [K,M] (row-contiguous operand); trans_b: B given as [N,K] (k-contiguous)
-    s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
-    if (s != RGCN_OK) break;
-    s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N);
-  } while (0);
-  if (A) (void)hipFree(A);
-  if (B) (void)hipFree(B);
-  if (C) (void)hipFree(C);
-  return s;
-}
-
-rgcn_status rgcn_debug_gemm_presplit(rgcn_ctx* c, int32_t tb, int32_t M, int32_t N, int32_t K, int32_t iters,
-                                     const float* a_host, const float* b_host, float* c_host, float* avg_ms) {
-  RGCN_NEED(c);
-  if (M <= 0 || N <= 0 || K <= 0 || !a_host || !b_host || !c_host) RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
-  float *A = nullptr, *B = nullptr, *C = nullptr;
-  void* F = nullptr;
-  rgcn_status s = RGCN_OK;
-  do {
-    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
-    if (hipMalloc(&F, 16 * gemm_bfrag_words(K, N)) != hipSuccess) { s = RGCN_ERR_NOMEM; break; }
-    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
-    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
-    const PresplitJob pj{B, F, tb ? K : N, K, N, tb ? 1 : 0};
-    if ((s = gemm_presplit_b(c, &pj, 1)) != RGCN_OK) break;
-    GemmBatch gb;
-    gb.bfrag = F;
-    gb.wide = 1;
-    s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
-    if (s != RGCN_OK) break;
-    if ((s = to_host(c, c_host, C, sizeof(float) * (size_t)M * N)) != RGCN_OK) break;
-    // RGCN_GEMM_TL_FILE: the per-wavefront stamps of ONE more launch (k_gemm_w8<.., DBG_TIMELINE / DBG_FINE>), raw uint64
-    if (const char* tlf = getenv("RGCN_GEMM_TL_FILE")) {
-      const size_t tb_bytes = gemm_w8_timeline_bytes(M, N, 1);
-      if (hipMalloc(&c->debug_buf, tb_bytes) != hipSuccess) { s = RGCN_ERR_NOMEM; break; }
-      (void)hipMemsetAsync(c->debug_buf, 0, tb_bytes, c->stream);
-      s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
-      std::vector<char> hb(tb_bytes);
-      if (s == RGCN_OK) s = to_host(c, hb.data(), c->debug_buf, tb_bytes);
-      (void)hipFree(c->debug_buf);
-      c->debug_buf = nullptr;
-      if (s != RGCN_OK) break;
-      if (FILE* f = fopen(tlf, "wb")) { fwrite(hb.data(), 1, tb_bytes, f); fclose(f); }
-    }
-    if (iters > 0 && avg_ms) {
-      if ((s = rgcn_timer_start(c)) != RGCN_OK) break;
-      for (int it = 0; it < iters && s == RGCN_OK; ++it)
-        s = gemm_f32(c, "debug_gemm", true, tb != 0, M, N, K, A, K, B, tb ? K : N, C, N, 1, &gb);
-      if (s != RGCN_OK) break;
-      float ms = 0.f;
-      if ((s = rgcn_timer_stop(c, &ms)) != RGCN_OK) break;
-      *avg_ms = ms / iters;
-    }
-  } while (0);
-  if (A) (void)hipFree(A);
-  if (B) (void)hipFree(B);
-  if (C) (void)hipFree(C);
-  if (F) (void)hipFree(F);
-  return s;
-}
-
-rgcn_status rgcn_debug_gemm_time(rgcn_ctx* c, int32_t ta, int32_t tb, int32_t M, int32_t N, int32_t K,
-                                 int32_t split_k, int32_t iters, const float* a_host,
-                                 const float* b_host, float* avg_ms) {
-  RGCN_NEED(c);
-  if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !a_host || !b_host || !avg_ms)
-    RGCN_FAIL(c, RGCN_ERR_INVALID, "bad arguments");
-  if (ta && tb) RGCN_FAIL(c, RGCN_ERR_UNSUPPORTED, "TT form not instantiated");
-  float *A = nullptr, *B = nullptr, *C = nullptr;
-  rgcn_status s = RGCN_OK;
-  do {
-    if ((s = dmalloc(c, &A, (size_t)M * K, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &B, (size_t)K * N, false)) != RGCN_OK) break;
-    if ((s = dmalloc(c, &C, (size_t)M * N)) != RGCN_OK) break;
-    if ((s = to_dev(c, A, a_host, sizeof(float) * (size_t)M * K)) != RGCN_OK) break;
-    if ((s = to_dev(c, B, b_host, sizeof(float) * (size_t)K * N)) != RGCN_OK) break;
-    int sk = split_k > 0 ? split_k : auto_split_k(M, N, K);
-    if ((size_t)sk * M * N > c->slab_floats) sk = 1;
-    for (int it = 0; it < 3 && s == RGCN_OK; ++it)
-      s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
-    if (s != RGCN_OK) break;
-    if ((s = rgcn_timer_start(c)) != RGCN_OK) break;
-    for (int it = 0; it < iters && s == RGCN_OK; ++it)
-      s = gemm_f32(c, "debug_gemm", ta == 0, tb != 0, M, N, K, A, ta ? M : K, B, tb ? K : N, C, N, sk);
-    if (s != RGCN_OK) break;
-    float ms = 0.f;
-    if ((s = rgcn_timer_stop(c, &ms)) != RGCN_OK) break;
-    *avg_ms = ms / iters;
-  } while (0);
-  if (A) (void)hipFree(A);
-  if (B) (void)hipFree(B);
-  if (C) (void)hipFree(C);
-  return s;
-}
-
-#endif  // RGCN_DEVTOOLS
 
 }  // extern "C"

@@ -435,8 +435,11 @@ namespace rgcn {
 // agent-scope fences, so on one GPU the event's own fence is dropped: 0.528-0.534 ms per headline step against 0.535-0.543,
 // three interleaved runs each on one box (release-to-device scope: 0.538-0.540; tools/gpu_r5_evflag.sh).  A sharded
 // context, whose buffers other ranks' kernels read and write, keeps the default.
-inline unsigned order_event_flags(const rgcn_ctx* c) {
-  return hipEventDisableTiming | (c->world == 1 ? hipEventDisableSystemFence : 0u);
+// kernel_only: the event orders kernels against kernels (fork, join).  Events that can also order copy-engine work -- a
+// graph set's ready / free (host staging copies and memsets on the prefetch stream), the sampler's draw, the decoder batch's
+// ready event, the step-begin marker -- keep the default fence: HIP documents no agent-scope release for SDMA operations.
+inline unsigned order_event_flags(const rgcn_ctx* c, bool kernel_only = false) {
+  return hipEventDisableTiming | (kernel_only && c->world == 1 ? hipEventDisableSystemFence : 0u);
 }
 
 // Runs the launches inside its scope on side stream k, ordered after everything already queued on

@@ -683,9 +683,11 @@ def test_relation_sharding_with_host_exchange(native, world, kind="block", nb=4,
 
 def test_backward_driven_by_layers_can_be_read_and_abandoned_between_layers(native):
     """One GPU, the phase API, minibatch schedule: the side-stream kernels of layer 2 (dW_self, the relation-weight
-    gradients) are joined into the main stream at the END OF LAYER 1 only (rgcn_api.hip, bwd_layer_partial).  A caller that
+    gradients) are joined into the main stream at the END OF LAYER 1 only (rgcn_schedule.hip, bwd_layer_partial).  A caller that
     reads layer 2's gradients between the layers gets the finished values (the getters wait for every stream), and a
-    backward pass abandoned there does not race the next forward pass (fwd_begin joins what was left)."""
+    backward pass abandoned there does not race what comes next -- a forward pass, ANOTHER backward pass (bwd_begin rewrites
+    the dS buffer the abandoned side kernels read), a new graph (its build rewrites their message lists): each of those
+    joins what was left (join_abandoned_side_work)."""
     V, R, d, L, nb, E = 300, 12, 20, 2, 4, 2000
     params, triples, masks, dcodes = make_case(V, R, d, L, "block", nb, E, seed=21)
     oacts, ograds = oracle.encoder_step(params, triples, V, L, "block", dcodes, dropout_masks=masks)
@@ -710,6 +712,26 @@ def test_backward_driven_by_layers_can_be_read_and_abandoned_between_layers(nati
             for name in ["W_self2", "W_f2", "W_b2"]:
                 assert_close(e.get_grad(name), ograds[name], rel=2e-4, name="between the layers: " + name)
             # ... and the pass is abandoned here: the next attempt starts with a forward pass
+        # abandoned again, then a second backward pass straight away (no forward pass in between) ...
+        forward()
+        e.backward_begin(buf)
+        e.backward_layer_partial(2)
+        e.backward_layer_finish(2)
+        e.backward_begin(buf)
+        for l in range(L, 0, -1):
+            e.backward_layer_partial(l)
+            e.backward_layer_finish(l)
+        e.backward_end()
+        g = e.get_grads()
+        for name in ["W_emb", "W_self1", "W_self2", "W_f1", "W_b2"]:
+            assert_close(g[name], ograds[name], rel=2e-4, name="second backward pass: " + name)
+        # ... and abandoned before a new graph is set: another graph first, then the old one again
+        forward()
+        e.backward_begin(buf)
+        e.backward_layer_partial(2)
+        e.backward_layer_finish(2)
+        e.set_graph(np.ascontiguousarray(triples[::-1][: E // 2]))
+        e.set_graph(triples)
         forward()
         e.backward_begin(buf)
         for l in range(L, 0, -1):
