@@ -4,8 +4,10 @@
     python tools/rocprof_summary.py gpurun_out/prof_r01 profiles/r01_rocprof_summary.md
 
 kernel-trace pass -> calls / average duration per kernel; PMC passes -> FETCH_SIZE / WRITE_SIZE (KB per
-dispatch).  HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports
-half the bytes of a wide coalesced read (MI355X_MICROARCH.md, section HBM), WRITE_SIZE is uncalibrated.
+dispatch).  Bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports
+half the bytes of a wide coalesced read (MI355X_MICROARCH.md, section HBM), WRITE_SIZE is uncalibrated.  Both derive from
+the L2's memory-side (fabric) request counters: they are L2 <-> fabric bytes -- Infinity-Cache hits are in them -- an upper
+bound on what reaches the HBM stacks, which is how the column is named.
 """
 import re
 import sqlite3
@@ -60,9 +62,9 @@ def main():
              "command: `%s` " % cmd +
              "(25 steps incl. warm-up); kernel-trace pass for durations, separate `--pmc FETCH_SIZE` / "
              "`--pmc WRITE_SIZE` passes for bytes.", "",
-             "HBM MB/launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 1e6 (gfx950 FETCH_SIZE half-count "
+             "L2<->fabric MB/launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 1e6: bytes between the XCDs' L2s and the fabric, Infinity-Cache hits included (gfx950 FETCH_SIZE half-count "
              "correction; WRITE_SIZE uncalibrated).", "",
-             "| kernel | calls | avg us | min us | max us | % of GPU time | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB/launch |",
+             "| kernel | calls | avg us | min us | max us | % of GPU time | FETCH_SIZE KB | WRITE_SIZE KB | L2<->fabric MB/launch |",
              "|---|---|---|---|---|---|---|---|---|"]
     for k, (n, tot, mn, mx) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
         f, w = fetch.get(k), write.get(k)
