@@ -1041,6 +1041,15 @@ def compact_line(out):
          "edges_per_s": t["minibatch_step"]["edges_per_s"],
          "hipgraph_ms": t["captured_step"]["ms_per_step_hipgraph_replay"],
          "stream_ms": t["captured_step"]["ms_per_step_stream_launched"],
+         # which mode the row's numbers are: ms_per_step = the whole iteration (device edge dropout + negatives + step),
+         # stream-launched -- the documented default for every configuration, config 5 included; hipgraph_ms / stream_ms =
+         # the SAME fixed step (rgcn_train_step_device) replayed from a captured hipGraph / launched on the four streams
+         "step": ("ms_per_step: stream-launched rgcn_train_step_minibatch_device (default mode); hipgraph_ms: "
+                  "rgcn_train_step_device replayed from a captured hipGraph; stream_ms: the same call stream-launched. "
+                  "Replay %s stream launch here (%.3f vs %.3f ms); DESIGN.md section 6"
+                  % ("beats" if t["captured_step"]["ms_per_step_hipgraph_replay"] < t["captured_step"]["ms_per_step_stream_launched"]
+                     else "does not beat", t["captured_step"]["ms_per_step_hipgraph_replay"],
+                     t["captured_step"]["ms_per_step_stream_launched"])),
          "top": [[k["kernel"], k["avg_us"], k["frac"]] for k in t["minibatch_step"].get("kernels", [])[:3]]}
         for t in out.get("train_steps", [])]
     ev = out.get("evaluation")

@@ -122,10 +122,24 @@ def test_gemm_with_presplit_weights_is_bitwise_the_staged_kernel(native, M, N, K
     A = rng.randn(M, K).astype(np.float32)
     B = (rng.randn(K, N) * np.exp(rng.uniform(-6, 6, (K, N)))).astype(np.float32)
     Bop = np.ascontiguousarray(B.T) if trans_b else B
-    with native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True) as eng:
-        eng.set_gemm_mode(mode)
-        staged = eng.debug_gemm(A, Bop, trans_b=trans_b, split_k=1)
-        pre = eng.debug_gemm_presplit(A, Bop, trans_b=trans_b)
+    # two kernels take a pre-split weight (csrc/gemm_bf16x3.hip picks by call site and tile count): the 128 x 128 /
+    # four-wavefront one whose fragments go straight to registers (B_PRE), and the 128 x 256 / eight-wavefront one that
+    # brings them in by LDS-DMA (gemm_bf16x3_w8.hip, round 6).  The devtools knob forces each in turn.
+    prev = os.environ.get("RGCN_GEMM_W8")
+    try:
+        with native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True) as eng:
+            eng.set_gemm_mode(mode)
+            staged = eng.debug_gemm(A, Bop, trans_b=trans_b, split_k=1)
+            os.environ["RGCN_GEMM_W8"] = "0"
+            pre_regs = eng.debug_gemm_presplit(A, Bop, trans_b=trans_b)
+            os.environ["RGCN_GEMM_W8"] = "3"
+            pre = eng.debug_gemm_presplit(A, Bop, trans_b=trans_b)
+    finally:
+        if prev is None:
+            os.environ.pop("RGCN_GEMM_W8", None)
+        else:
+            os.environ["RGCN_GEMM_W8"] = prev
+    np.testing.assert_array_equal(pre_regs, staged)
     np.testing.assert_array_equal(pre, staged)
     ref = A.astype(np.float64) @ B.astype(np.float64)
     mag = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
