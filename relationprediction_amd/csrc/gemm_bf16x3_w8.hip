@@ -50,22 +50,6 @@ __device__ __forceinline__ void aload(f32x4& dst, const float* p) {
 __device__ __forceinline__ void aload_s(f32x4& dst, uint32_t voff, const float* sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-// three 1 KB pieces of the fragment table -> LDS at lds_addr, + 1 KB, + 2 KB (the immediate offset moves both addresses)
-__device__ __forceinline__ void dma3(uint32_t voff, const u32x4* sbase, uint32_t lds_addr) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_addr)
-      : "memory");
-}
-
 // DBG (devtools builds only; 0 in the product): ablation switches and the per-wavefront timeline of tools/gemm_w8_lab.py
 enum : int { DBG_NO_MFMA = 1, DBG_NO_SPLIT = 2, DBG_NO_FRAG = 4, DBG_NO_DMA = 8, DBG_NO_ALOAD = 16, DBG_NO_STORE = 32,
               DBG_TIMELINE = 64, DBG_FINE = 128, DBG_NT_STORE = 256 };
@@ -86,6 +70,8 @@ __device__ __forceinline__ void dma1(uint32_t voff, const u32x4* sbase, uint32_t
       : "memory");
 }
 
+// (192 registers, not the 193 the allocator would take: two wavefronts of this kernel then leave a SIMD 128 registers, one
+// wavefront of the 126-128-register layer kernels)
 template <int TERMS, int DBG = 0>
 __global__ void __launch_bounds__(WNTH, 2) __attribute__((amdgpu_num_vgpr(192))) k_gemm_w8(XArgs g) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -162,7 +148,7 @@ __global__ void __launch_bounds__(WNTH, 2) __attribute__((amdgpu_num_vgpr(192)))
   // stage s -> its loads.  Stages past the end load zeros (the count of operations in flight stays what the waits assume).
   // In a step the four operations go out one by one BEHIND MFMAs (issue_part 0..2: B's pieces, 3: A): eight wavefronts
   // issuing 32 of them at the top of a step kept the CU's address unit busy for ~300 cycles with no MFMA in flight
-  // (profiles/r06_gemm_w8_lab.md).
+  // (profiles/r06_gemm_w8.md section 2).
   auto issue_part = [&](int s, auto slot, auto part) {
     constexpr int P = decltype(slot)::value;
     constexpr int Q = decltype(part)::value;
