@@ -146,6 +146,37 @@ def test_gemm_with_presplit_weights_is_bitwise_the_staged_kernel(native, M, N, K
     assert float((np.abs(pre - ref) / mag).max()) < 2e-6
 
 
+def test_presplit_weight_kernels_on_random_shapes(native):
+    """The two kernels that take a pre-split weight, on 24 seeded random shapes (M 1..700, N and K multiples of 4 up to 520 /
+    260: one to six row tiles, one to three 256-column tiles, K from a quarter of a k-tile to 16 k-tiles -- fewer stages than
+    the eight-wavefront kernel's ring is deep, the partial last tile, the stages past the end): bitwise the staged kernel."""
+    rng = np.random.RandomState(20260930)
+    prev = os.environ.get("RGCN_GEMM_W8")
+    try:
+        with native.Engine(16, 2, 8, 1, "block", 2, max_edges=4, devtools=True) as eng:
+            eng.set_gemm_mode(6)
+            for case in range(24):
+                M = int(rng.randint(1, 701))
+                N = 4 * int(rng.randint(1, 131))
+                K = 4 * int(rng.randint(1, 66))
+                trans_b = bool(rng.randint(0, 2))
+                A = rng.randn(M, K).astype(np.float32)
+                B = (rng.randn(K, N) * np.exp(rng.uniform(-4, 4, (K, N)))).astype(np.float32)
+                Bop = np.ascontiguousarray(B.T) if trans_b else B
+                os.environ.pop("RGCN_GEMM_W8", None)
+                staged = eng.debug_gemm(A, Bop, trans_b=trans_b, split_k=1)
+                for code in ("0", "3"):
+                    os.environ["RGCN_GEMM_W8"] = code
+                    got = eng.debug_gemm_presplit(A, Bop, trans_b=trans_b)
+                    np.testing.assert_array_equal(got, staged, err_msg="case %d: M %d N %d K %d trans_b %s kernel %s"
+                                                  % (case, M, N, K, trans_b, code))
+    finally:
+        if prev is None:
+            os.environ.pop("RGCN_GEMM_W8", None)
+        else:
+            os.environ["RGCN_GEMM_W8"] = prev
+
+
 def test_gemm_modes_are_fp32_accurate(native):
     """The split evaluation must be as accurate as the fp32 MFMA on the encoder's own shapes: error against
     float64, normalised by sum |a||b| (the scale fp32 rounding errors live on), within 1.5x of mode 0's, and
