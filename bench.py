@@ -391,14 +391,14 @@ def measure(workload, args, rk, steps, warmup, full):
         devs = allgather_scalar(float(dev_seen if dev_seen >= 0 else device))
         ranks_seen = allgather_scalar(float(n_seen))
         problems = []
-        if n_seen != world:
+        if n_seen >= 0 and n_seen != world:      # (-1: the bound library has no ncclCommCount -- nothing to compare)
             problems.append("the collective library reports %d ranks, the launcher started %d" % (n_seen, world))
         if r_seen >= 0 and r_seen != rank:
             problems.append("rank %d is rank %d of the communicator" % (rank, r_seen))
         share = os.environ.get("RGCN_BENCH_SHARE_GPU") == "1"      # tests: N ranks on ONE GPU over a stand-in collective
         if not share and len(set(int(x) for x in devs)) != world:
             problems.append("ranks share a device: devices by rank = %s" % [int(x) for x in devs])
-        if any(int(x) != world for x in ranks_seen):
+        if n_seen >= 0 and any(int(x) != world for x in ranks_seen):
             problems.append("ranks disagree about the communicator's size: %s" % [int(x) for x in ranks_seen])
         if problems:
             sys.stderr.write("bench.py --gpus %d: multi-GPU self-check FAILED on rank %d: %s\n" % (world, rank, "; ".join(problems)))
