@@ -462,6 +462,23 @@ def measure(workload, args, rk, steps, warmup, full):
     ms_per_step = wall * 1e3 / steps
     value = E_g * steps / wall
 
+    # ---- the same loop once the device has settled (informative, never `value`): a fresh process's first ~30 steps run
+    # 6-13 % slower than the steady state (profiles/r05_first_steps_series.txt: every kernel alike, the device's power
+    # management after idle), and the driver's `--steps 20 --warmup 5` measures exactly those
+    steady = None
+    if full and world == 1:
+        n_s = 40
+        run(15, 2500)
+        barrier()
+        t1 = time.perf_counter()
+        run(n_s, 2600)
+        eng.sync()
+        barrier()
+        wall_s = time.perf_counter() - t1
+        steady = {"ms_per_step": round(wall_s * 1e3 / n_s, 4), "value": round(E_g * n_s / wall_s, 1), "unit": "edges/s",
+                  "steps": n_s, "after_steps": warmup + steps + 15,
+                  "note": "the same loop continued after the timed region; informative only -- `value` is the timed region's"}
+
     # ---- the same step with the dense contractions on the fp32 MFMA (mode 0), for reference
     fp32_ref = None
     if full and args.gemm_mode != 0 and not args.no_fp32_reference:
@@ -629,6 +646,7 @@ def measure(workload, args, rk, steps, warmup, full):
             "message_edges_per_s": round(2 * L * value, 1),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,
+            "steady_state": steady,
         }
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
@@ -1030,6 +1048,8 @@ def compact_line(out):
         line["cpu_baseline_reference_code"] = out["cpu_baseline_reference_code"]
     if out.get("fp32_mfma_reference"):
         line["fp32_mfma_reference_ms_per_step"] = out["fp32_mfma_reference"]["ms_per_step"]
+    if out.get("steady_state"):
+        line["steady_state"] = out["steady_state"]
     line["top_kernels"] = [[k["kernel"], k["launches_per_step"], k["avg_us"], k["frac"]] for k in out.get("kernels", [])[:6]]
     line["workloads"] = [
         {"workload": w["config"]["workload"], "value": w["value"], "ms_per_step": w["ms_per_step"],
