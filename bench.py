@@ -356,7 +356,10 @@ def measure(workload, args, rk, steps, warmup, full):
 
     # RGCN_BENCH_SHARE_GPU=1 (tests only, with RGCN_RCCL_LIBRARY pointing at the shared-memory collective of
     # tests/collective_double): every rank on device 0, to run the multi-process path on a one-GPU box
-    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" else rk.local_rank
+    # A launcher that masks the visible devices per rank leaves every rank with ONE device, index 0: take LOCAL_RANK only
+    # while the process sees that many devices (which GPU it is gets checked by PCI address below).
+    n_visible, _ = _native.Engine.device_info(0)
+    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" or (world > 1 and n_visible == 1) else rk.local_rank
     eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
                          device=device, rank=rank, world=world)
     if os.environ.get("RGCN_STREAMS", "1") == "0":      # bench.py's own switch (the PMC passes run on one stream)
@@ -385,10 +388,13 @@ def measure(workload, args, rk, steps, warmup, full):
     if world > 1:
         # First contact with a multi-GPU node must diagnose itself: the collective library has to SEE `world` ranks, and no two
         # ranks may sit on one device (a mis-set LOCAL_RANK / HIP_VISIBLE_DEVICES gives N processes on GPU 0 that "scale"
-        # at 1/N).  What RCCL reports (ncclCommCount, ncclCommCuDevice) and the PCI bus id of the HIP device are gathered
+        # at 1/N).  What RCCL reports (ncclCommCount, ncclCommCuDevice) and the PCI address of that HIP device are gathered
         # over the communicator itself; any mismatch ends the run with a non-zero exit instead of a number.
         n_seen, r_seen, dev_seen = eng.comm_info()
-        devs = allgather_scalar(float(dev_seen if dev_seen >= 0 else device))
+        pci = _native.Engine.device_info(dev_seen if dev_seen >= 0 else device)[1]
+        # (domain, bus << 8 | device) as two exact floats; an unknown address falls back to the device index
+        devs = list(zip(allgather_scalar(float(pci >> 16) if pci >= 0 else -1.0),
+                        allgather_scalar(float(pci & 0xffff) if pci >= 0 else float(device))))
         ranks_seen = allgather_scalar(float(n_seen))
         problems = []
         if n_seen >= 0 and n_seen != world:      # (-1: the bound library has no ncclCommCount -- nothing to compare)
@@ -396,8 +402,9 @@ def measure(workload, args, rk, steps, warmup, full):
         if r_seen >= 0 and r_seen != rank:
             problems.append("rank %d is rank %d of the communicator" % (rank, r_seen))
         share = os.environ.get("RGCN_BENCH_SHARE_GPU") == "1"      # tests: N ranks on ONE GPU over a stand-in collective
-        if not share and len(set(int(x) for x in devs)) != world:
-            problems.append("ranks share a device: devices by rank = %s" % [int(x) for x in devs])
+        if not share and len(set(devs)) != world:
+            problems.append("ranks share a device: PCI (domain, bus:device) by rank = %s"
+                            % [(int(a), "%02x:%02x" % (int(b) >> 8, int(b) & 0xff)) for a, b in devs])
         if n_seen >= 0 and any(int(x) != world for x in ranks_seen):
             problems.append("ranks disagree about the communicator's size: %s" % [int(x) for x in ranks_seen])
         if problems:

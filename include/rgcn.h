@@ -348,6 +348,11 @@ rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* ctx, float* dev, int64_t count);
  * come up with N ranks" from inside a run (bench.py prints it as "rccl_ranks").  -1 where there is no communicator
  * (world == 1 / before rgcn_comm_init) or the bound library lacks the entry point. */
 rgcn_status rgcn_comm_info(rgcn_ctx* ctx, int32_t* comm_ranks, int32_t* comm_rank, int32_t* comm_device);
+/* Context-free: how many HIP devices this process sees (0 without a GPU) and, for 0 <= device < count, the PCI address
+ * of that device as domain << 16 | bus << 8 | device (-1 otherwise).  A launcher that masks the visible devices per
+ * rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) makes every rank's GPU "device 0": bench.py --gpus N picks its
+ * device by this count and compares PCI addresses, not indices, when it checks that no two ranks share a GPU. */
+rgcn_status rgcn_device_info(int32_t device, int32_t* count, int64_t* pci_address);
 
 /* Phase API: the same forward/backward cut at the points where a sharded run exchanges data.
  * rgcn_forward == begin; for l: partial(l) [all-reduce EXCHANGE] finish(l).

@@ -116,6 +116,7 @@ _SIGS = {
     "rgcn_set_gemm_mode": (C.c_int32, [_P, C.c_int32]),
     "rgcn_set_fusion": (C.c_int32, [_P, C.c_int32]),
     "rgcn_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rgcn_device_info": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "rgcn_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "rgcn_profile_reset": (C.c_int32, [_P]),
     "rgcn_profile_count": (C.c_int32, [_P]),
@@ -606,6 +607,16 @@ class Engine:
         if st != 0:
             raise RgcnError(st, (lib.rgcn_last_error(None) or b"").decode())
         return bytes(buf)
+
+    @staticmethod
+    def device_info(device=0):
+        """(HIP devices this process sees, PCI address of `device` as domain << 16 | bus << 8 | device, or -1)"""
+        lib = load_library()
+        n, pci = C.c_int32(0), C.c_int64(-1)
+        st = lib.rgcn_device_info(int(device), C.byref(n), C.byref(pci))
+        if st != 0:
+            raise RgcnError(st, (lib.rgcn_last_error(None) or b"").decode())
+        return n.value, pci.value
 
     def comm_init(self, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))

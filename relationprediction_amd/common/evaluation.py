@@ -8,7 +8,9 @@ chunk of 1000 triples, :334-389).  What changes is where the work happens: the r
 and materialises a [1000, V] score matrix in numpy for every chunk and side; here the graph is encoded once per
 `compute_scores` and the ranks are counted on the device (rgcn_rank_device, csrc/ranking.hip).
 
-Only Metric=MRR is built (Accuracy belongs to the *_accuracy.txt datasets no BASELINE config uses)."""
+Metric=Accuracy (the *_accuracy.txt datasets: (positive, negative) pairs on consecutive lines; no BASELINE config uses
+it) is the share of pairs whose positive outscores its negative, from one `model.score` of the listed triples (:178-209,
+:311-326)."""
 import math
 
 import numpy as np
@@ -127,6 +129,38 @@ class MrrScore(object):
                 print(str(raw) + '\t' + str(filtered), file=outfile)
 
 
+class AccuracySummary(object):
+    """code/common/evaluation.py:178-196 (`results` is per summary here; the reference keeps ONE class-level dict)"""
+
+    def __init__(self, predictions):
+        self.results = {'Filtered': {}, 'Raw': {}}
+        self.results['Filtered'][self.accuracy_string()] = np.mean(predictions)
+
+    def dump_degrees(self, in_file, out_file):
+        pass
+
+    def accuracy_string(self):
+        return 'Accuracy'
+
+    def pretty_print(self):
+        for item in [self.accuracy_string()]:
+            print(item, end='\t')
+            print(str(round(self.results['Filtered'][item], 3)), end='\n')
+
+
+class AccuracyScore(object):
+    """code/common/evaluation.py:199-209"""
+
+    def append_all(self, evaluations):
+        self.predictions = evaluations
+
+    def summarize(self):
+        self.get_summary().pretty_print()
+
+    def get_summary(self):
+        return AccuracySummary(self.predictions)
+
+
 class Scorer(object):
     chunk_size = 1000
 
@@ -180,8 +214,19 @@ class Scorer(object):
     def compute_scores(self, triples, verbose=False):
         if self.settings['Metric'] == 'MRR':
             return self.compute_mrr_scores(triples, verbose=verbose)
-        raise NotImplementedError("Evaluation.Metric=%s (only MRR is built; SURVEY.md section 2)"
+        if self.settings['Metric'] == 'Accuracy':
+            return self.compute_accuracy_scores(triples, verbose=verbose)
+        raise NotImplementedError("Evaluation.Metric=%s (MRR and Accuracy are what the reference has)"
                                   % self.settings['Metric'])
+
+    def compute_accuracy_scores(self, triples, verbose=False):
+        """code/common/evaluation.py:311-326: rows 2k / 2k + 1 are a (positive, negative) pair; a tie counts as wrong"""
+        score = AccuracyScore()
+        if verbose:
+            print("Evaluating accuracies...")
+        score_vector = np.asarray(self.model.score(triples))
+        score.append_all(score_vector[::2] > score_vector[1::2])
+        return score
 
     def compute_mrr_scores(self, triples, verbose=False):
         triples = np.asarray(triples)

@@ -1126,6 +1126,24 @@ rgcn_status rgcn_comm_info(rgcn_ctx* c, int32_t* comm_ranks, int32_t* comm_rank,
   return comm_info(c, comm_ranks, comm_rank, comm_device);
 }
 
+rgcn_status rgcn_device_info(int32_t device, int32_t* count, int64_t* pci_address) {
+  if (!count || !pci_address) return RGCN_ERR_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  *count = n;
+  *pci_address = -1;
+  if (device < 0 || device >= n) return RGCN_OK;
+  int dom = 0, bus = 0, dev = 0;
+  if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+      hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+      hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return RGCN_ERR_HIP;
+  }
+  *pci_address = ((int64_t)dom << 16) | ((int64_t)(bus & 0xff) << 8) | (int64_t)(dev & 0xff);
+  return RGCN_OK;
+}
+
 rgcn_status rgcn_comm_allreduce_sum(rgcn_ctx* c, float* dev, int64_t count) {
   RGCN_NEED(c);
   return comm_allreduce(c, dev, count);

@@ -19,16 +19,16 @@ from .optimization.optimize import build_hip
 
 
 def load_dataset(dataset, metric='MRR'):
-    """code/train.py:21-47.  Only the MRR protocol is built (the reference's Accuracy branch reads the
-    *_accuracy.txt files and scores with compute_accuracy_scores): anything else is refused HERE, at start-up,
-    not at the first early-stopping check thousands of iterations in."""
-    if metric != 'MRR':
-        raise NotImplementedError("Evaluation.Metric = %r: only 'MRR' is implemented" % (metric,))
+    """code/train.py:21-47.  Metric 'Accuracy' reads valid_accuracy.txt / test_accuracy.txt instead of valid.txt /
+    test.txt (:32-35).  A metric the reference does not have is refused HERE, at start-up, not at the first
+    early-stopping check thousands of iterations in."""
+    if metric not in ('MRR', 'Accuracy'):
+        raise NotImplementedError("Evaluation.Metric = %r: the reference has 'MRR' and 'Accuracy'" % (metric,))
     relations_path = dataset + '/relations.dict'
     entities_path = dataset + '/entities.dict'
     splits = {}
     for name in ('train', 'valid', 'test'):
-        path = dataset + '/' + name + '.txt'
+        path = dataset + '/' + name + ('_accuracy' if metric == 'Accuracy' and name != 'train' else '') + '.txt'
         splits[name] = np.array(io.read_triplets_as_list(path, entities_path, relations_path), dtype=np.int32)
     return splits, io.read_dictionary(entities_path), io.read_dictionary(relations_path)
 
@@ -151,7 +151,9 @@ def main(argv=None):
 
     def score_validation_data(validation_data):
         score_summary = scorer.compute_scores(validation_data, verbose=False).get_summary()
-        early_stopping = score_summary.results['Filtered'][score_summary.mrr_string()]
+        lookup_string = (score_summary.mrr_string() if evaluation_settings['Metric'] == 'MRR'
+                         else score_summary.accuracy_string())               # code/train.py:116-121
+        early_stopping = score_summary.results['Filtered'][lookup_string]
         score_summary = scorer.compute_scores(test_triplets, verbose=False).get_summary()
         score_summary.pretty_print()
         return early_stopping

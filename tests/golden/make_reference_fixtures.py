@@ -190,6 +190,39 @@ class ScoreTableModel(object):
         return [self._sig((self.codes @ (self.codes[s] * self.rel[r])).astype(np.float32)) for s, r, o in triples]
 
 
+    def score(self, triples):
+        """model.score (model.py:59-62): the decoder's prediction for the listed triples"""
+        t = np.asarray(triples)
+        return self._sig(np.sum(self.codes[t[:, 0]] * self.rel[t[:, 1]] * self.codes[t[:, 2]], axis=1).astype(np.float32))
+
+
+def accuracy_cases(m):
+    """Evaluation.Metric = Accuracy (evaluation.py:178-209, 311-331): the *_accuracy.txt files hold (positive, negative)
+    pairs on consecutive lines; the score is the share of pairs whose positive outscores its negative."""
+    cases = []
+    for seed, V, R, d, pairs, scale in ((11, 30, 3, 6, 40, 1.0), (12, 20, 2, 4, 7, 1.0), (13, 25, 3, 5, 60, 40.0)):
+        rng = np.random.RandomState(seed)
+        triples = np.stack([rng.randint(0, V, 2 * pairs), rng.randint(0, R, 2 * pairs), rng.randint(0, V, 2 * pairs)], 1)
+        if seed == 12:
+            triples[5] = triples[4]           # a pair with equal scores: `>` counts it as wrong
+        table = np.random.RandomState(seed + 50)
+        codes = (table.randn(V, d) * scale).astype(np.float32)      # scale 40: saturated sigmoids, exact ties
+        rel = table.randn(R, d).astype(np.float32)
+        m.evaluation.AccuracySummary.results = {'Filtered': {}, 'Raw': {}}    # (a class attribute there: start clean)
+        scorer = m.evaluation.Scorer({"Metric": "Accuracy"})
+        scorer.register_model(ScoreTableModel(codes, rel))
+        score = scorer.compute_scores(triples, verbose=False)
+        summary = score.get_summary()
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            summary.pretty_print()
+        cases.append({"seed": seed, "entities": V, "relations": R, "dim": d, "pairs": pairs, "scale": scale,
+                      "triples": jsonable(triples), "predictions": [bool(x) for x in score.predictions],
+                      "results": jsonable(summary.results), "accuracy_string": summary.accuracy_string(),
+                      "pretty_print": out.getvalue()})
+    return cases
+
+
 def scorer_cases(m):
     cases = []
     for seed, V, R, d, sizes, scale in ((2, 40, 4, 8, (300, 60, 50), 1.0), (7, 25, 3, 6, (120, 30, 1100), 1.0),
@@ -284,7 +317,7 @@ def main():
     m = reference_modules()
     tmp = tempfile.mkdtemp()
     fixture = {"settings_text": SETTINGS_TEXT, "stack": {}, "negative_sampler": negative_sampler_cases(m),
-               "scorer": scorer_cases(m), "neighborhood_sampler": neighborhood_sampler_cases()}
+               "scorer": scorer_cases(m), "accuracy": accuracy_cases(m), "neighborhood_sampler": neighborhood_sampler_cases()}
     for name, (extra, losses, scores) in SCENARIOS.items():
         fixture["stack"][name] = run_stack_scenario(m, extra, losses, scores, tmp)
     fixture["io"] = io_cases(load("ref_io", REF + "/common/io.py"), tmp)

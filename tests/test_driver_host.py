@@ -160,7 +160,7 @@ def test_scorer_mrr_against_brute_force():
     assert model.calls[0] == (16, False) and model.calls[1] == (16, True)   # subjects first (predict_object=False)
     summary.pretty_print()
     with pytest.raises(NotImplementedError):
-        evaluation.Scorer({'Metric': 'Accuracy'}).compute_scores(test)
+        evaluation.Scorer({'Metric': 'AUC'}).compute_scores(test)
 
 
 # ------------------------------------------------------------------ optimizer stack
@@ -306,11 +306,24 @@ def test_minibatch_transform_semantics():
 
 
 def test_unsupported_metric_and_checkpoint_directory(tmp_path):
-    """Evaluation.Metric other than MRR is refused when the dataset is loaded (the reference switches to its
-    accuracy files there); Model.save creates the checkpoint's directory and load restores by stored position"""
+    """An Evaluation.Metric the reference does not have is refused when the dataset is loaded; 'Accuracy' switches the
+    validation / test splits to the *_accuracy.txt files (code/train.py:32-35); Model.save creates the checkpoint's
+    directory and load restores by stored position"""
     from relationprediction_amd import train
     with pytest.raises(NotImplementedError, match="MRR"):
-        train.load_dataset(str(tmp_path), metric='Accuracy')
+        train.load_dataset(str(tmp_path), metric='AUC')
+    (tmp_path / "entities.dict").write_text("0\ta\n1\tb\n2\tc\n")
+    (tmp_path / "relations.dict").write_text("0\tr\n1\tq\n")
+    (tmp_path / "train.txt").write_text("a\tr\tb\nb\tq\tc\n")
+    (tmp_path / "valid.txt").write_text("a\tq\tc\n")
+    (tmp_path / "test.txt").write_text("c\tq\ta\n")
+    (tmp_path / "valid_accuracy.txt").write_text("a\tr\tb\na\tr\tc\n")
+    (tmp_path / "test_accuracy.txt").write_text("b\tq\tc\nb\tq\ta\nc\tr\ta\nb\tr\ta\n")
+    splits, entities, relations = train.load_dataset(str(tmp_path), metric='Accuracy')
+    assert splits['train'].tolist() == [[0, 0, 1], [1, 1, 2]]
+    assert splits['valid'].tolist() == [[0, 0, 1], [0, 0, 2]]                          # (positive, negative) pairs
+    assert splits['test'].tolist() == [[1, 1, 2], [1, 1, 0], [2, 0, 0], [1, 0, 0]]
+    assert train.load_dataset(str(tmp_path), metric='MRR')[0]['valid'].tolist() == [[0, 1, 2]]
     from relationprediction_amd.model import Model
 
     class W(object):

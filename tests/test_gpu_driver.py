@@ -120,6 +120,40 @@ def test_train_driver_end_to_end(tmp_path, capsys, concat, nb, extra):
     assert np.abs(raw - host_raw).max() <= 1 and (filt == raw).all() # filter = gold only -> filtered == raw
 
 
+def test_train_driver_with_the_accuracy_metric(tmp_path, capsys):
+    """Evaluation.Metric = Accuracy end to end (code/train.py:32-35,116-121; evaluation.py:311-326): validation / test
+    data are the *_accuracy.txt pair files, the early-stopping score is the share of pairs whose positive outscores its
+    negative (model.score: encoder forward on the device, DistMult on the codes), and a trained model beats a coin."""
+    from relationprediction_amd import train
+    data = str(tmp_path / "data")
+    train_triples = write_dataset(data)
+    rng = np.random.RandomState(5)
+    known = {tuple(t) for t in train_triples.tolist()}
+    for name, lo in (("valid_accuracy", 0), ("test_accuracy", 100)):
+        with open(os.path.join(data, name + ".txt"), "w") as f:
+            for s, r, o in train_triples[lo:lo + 100]:                  # (positive, corrupted object) on consecutive lines
+                bad = int(rng.randint(200))
+                while (s, r, bad) in known:
+                    bad = int(rng.randint(200))
+                f.write("e%d\tr%d\te%d\ne%d\tr%d\te%d\n" % (s, r, o, s, r, bad))
+    os.makedirs(str(tmp_path / "models"))
+    settings = tmp_path / "toy.exp"
+    settings.write_text((SETTINGS % dict(nb=4, concat="Yes", exp=str(tmp_path / "models" / "Toy")))
+                        .replace("Metric=MRR", "Metric=Accuracy"))
+    np.random.seed(0)
+    model, iterations = train.main(["--settings", str(settings), "--dataset", data, "--max-iterations", "60"])
+    out = capsys.readouterr().out
+    assert iterations == 60
+    checks = [float(l.split("Result: ")[1]) for l in out.splitlines() if l.startswith("Tested validation score")]
+    # positives seen in training against random objects: a coin at the start, better with every check (0.48 / 0.52 / 0.60)
+    assert len(checks) == 3 and checks[-1] >= 0.55 and checks[-1] > checks[0], checks
+    printed = [l for l in out.splitlines() if l.startswith("Accuracy\t")]
+    assert len(printed) == 3 and "MRR" not in out                       # the test-set summary of every check
+    valid = np.array(train.load_dataset(data, "Accuracy")[0]["valid"])
+    scores = model.score(valid)
+    assert scores.shape == (200,) and abs(checks[-1] - np.mean(scores[::2] > scores[1::2])) <= 0.05   # (<= one step apart)
+
+
 def test_lookahead_draw_leaves_the_trajectory_unchanged(tmp_path, capsys, monkeypatch):
     """A device-sampled batch is a function of its seed: drawing it one iteration early (HipOptimizer.presample, three
     batch buffers in turn) trains to the same weights, bit for bit, as drawing it when its graph is prepared."""

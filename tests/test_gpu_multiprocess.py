@@ -83,6 +83,16 @@ def test_bench_multi_rank_prints_one_json_line_last(collective, world):
     check_multi_rank_line(r, world)
 
 
+def test_bench_refuses_ranks_that_share_a_gpu(collective):
+    """Two ranks on a box whose launcher leaves them ONE visible device, without the tests' override: both take device 0
+    (rgcn_device_info: one device visible), the communicator comes up, and the self-check -- PCI addresses gathered over
+    the communicator -- ends the run with status 3 and says why, instead of printing a number that "scales" at 1/N."""
+    r = launch(2, 29671, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-steps", "0"], collective, {})
+    assert r.returncode != 0
+    assert "multi-GPU self-check FAILED" in r.stderr and "ranks share a device" in r.stderr, r.stderr[-3000:]
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_spawns_its_own_ranks_without_a_launcher(collective, world):
     """`python3 bench.py --gpus N` as the driver calls it (no torch.distributed.run, no WORLD_SIZE): the script starts

@@ -193,6 +193,49 @@ class TableRankModel(object):
         return oracle.distmult_ranks(self.codes, self.rel, triplets, predict_object, known)
 
 
+class TableScoreModel(object):
+    """model.score for the Accuracy metric: sigmoid DistMult scores of the listed triples from fixed tables, fp32"""
+
+    def __init__(self, codes, rel):
+        self.codes, self.rel = codes, rel
+
+    def score(self, triples):
+        t = np.asarray(triples)
+        x = np.sum(self.codes[t[:, 0]] * self.rel[t[:, 1]] * self.codes[t[:, 2]], axis=1).astype(np.float32)
+        with np.errstate(over="ignore"):
+            return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", FIX["accuracy"], ids=lambda c: "seed%d" % c["seed"])
+def test_accuracy_metric_equals_the_reference_scorer(case):
+    """Evaluation.Metric = Accuracy against what the reference's own Scorer returned for the same pairs and score tables
+    (reference: code/common/evaluation.py:178-209, 311-331): per-pair outcomes, the summary, the printed line; a tie
+    counts as wrong."""
+    table = np.random.RandomState(case["seed"] + 50)
+    codes = (table.randn(case["entities"], case["dim"]) * case["scale"]).astype(np.float32)
+    rel = table.randn(case["relations"], case["dim"]).astype(np.float32)
+    triples = np.array(case["triples"])
+    assert len(triples) == 2 * case["pairs"]
+    scorer = evaluation.Scorer({'Metric': 'Accuracy'})
+    scorer.register_model(TableScoreModel(codes, rel))
+    score = scorer.compute_scores(triples, verbose=False)
+    assert [bool(x) for x in score.predictions] == case["predictions"]
+    summary = score.get_summary()
+    assert summary.accuracy_string() == case["accuracy_string"]
+    assert summary.results['Raw'] == case["results"]["Raw"] == {}
+    assert_same(summary.results['Filtered']['Accuracy'], case["results"]["Filtered"]["Accuracy"], "Accuracy")
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        summary.pretty_print()
+        score.summarize()
+    assert out.getvalue() == 2 * case["pretty_print"]
+    if case["seed"] == 12:
+        assert np.array_equal(triples[4], triples[5]) and not score.predictions[2]      # the tied pair
+    # a second summary does not see the first one's entries (the reference shares one class-level dict)
+    assert evaluation.AccuracySummary([True]).results['Filtered'] == {'Accuracy': 1.0}
+    assert summary.results['Filtered']['Accuracy'] == case["results"]["Filtered"]["Accuracy"]
+
+
 @pytest.mark.parametrize("case", FIX["scorer"], ids=lambda c: "seed%d" % c["seed"])
 def test_scorer_equals_the_reference_scorer(case):
     V, R, d = case["entities"], case["relations"], case["dim"]
