@@ -332,70 +332,86 @@ def kernel_table(prof, steps, args, in_pipeline=None):
     return kernels
 
 
-def measure(workload, args, rk, steps, warmup, full):
-    """One workload on this rank's engine: timed steps (barrier + sync on both sides, max over ranks), then the
-    per-kernel passes.  full = the headline extras (fp32-MFMA reference run, CPU baseline)."""
-    import numpy as np
-    from relationprediction_amd import _native
-    from relationprediction_amd.sharding import lpt_partition
-    from relationprediction_amd.common.shared_functions import init_encoder_params
+class EncoderBench:
+    """One encoder workload on this rank's engine: the engine, two alternating minibatches resident in HBM, the step loop
+    and the legs that are measured on it.  `measure` below strings the legs together."""
 
-    rank, world = rk.rank, rk.world
-    graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[workload]
-    triples = load_graph(graph_name)
-    assert triples.shape[0] == E_g
-    # a second minibatch of the same size so that consecutive steps see different graphs (as in training, where
-    # t_func samples a new one every step): steps alternate A, B, A, B ...
-    if graph_name == "fb237_minibatch":
-        pool = load_graph("fb237_valid_test")
-        triples_b = np.ascontiguousarray(pool[np.random.RandomState(7).choice(pool.shape[0], size=E_g, replace=False)])
-    else:
-        triples_b = np.ascontiguousarray(triples[np.random.RandomState(7).permutation(E_g)])
-    params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
-    dcodes = (np.random.RandomState(2).randn(V, d) * 1e-3).astype(np.float32)
+    def __init__(self, workload, args, rk):
+        import numpy as np
+        from relationprediction_amd import _native
+        from relationprediction_amd.sharding import lpt_partition
+        from relationprediction_amd.common.shared_functions import init_encoder_params
 
-    # RGCN_BENCH_SHARE_GPU=1 (tests only, with RGCN_RCCL_LIBRARY pointing at the shared-memory collective of
-    # tests/collective_double): every rank on device 0, to run the multi-process path on a one-GPU box
-    # A launcher that masks the visible devices per rank leaves every rank with ONE device, index 0: take LOCAL_RANK only
-    # while the process sees that many devices (which GPU it is gets checked by PCI address below).
-    n_visible, _ = _native.Engine.device_info(0)
-    device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" or (world > 1 and n_visible == 1) else rk.local_rank
-    eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
-                         device=device, rank=rank, world=world)
-    if os.environ.get("RGCN_STREAMS", "1") == "0":      # bench.py's own switch (the PMC passes run on one stream)
-        eng.set_overlap(False)
-    eng.set_params(params)
-    if world > 1:
-        # One rank per GPU (launched by torch.distributed.run, which only provides the environment).
-        # The process keeps ONE ROCm stack: no torch import here; the 128-byte RCCL id travels through a
-        # file on this node (single-node contract), everything else (barriers, max over ranks) rides on
-        # the library's own RCCL communicator.
-        owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
-        eng.set_relation_owner(owner)
-        from relationprediction_amd.sharding import share_unique_id
-        uid = share_unique_id(rank, rk.rdv_path, _native.Engine.comm_unique_id)
-        eng.comm_init(uid)
-    rccl_ranks = eng.comm_info()[0] if world > 1 else None
-    comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
+        self.np, self.native = np, _native
+        self.workload, self.args, self.rk = workload, args, rk
+        self.rank, self.world = rank, world = rk.rank, rk.world
+        self.graph_name, self.V, self.R, self.d, self.L, self.kind, self.nb, self.E_g = WORKLOADS[workload]
+        graph_name, V, R, d, L, kind, nb, E_g = WORKLOADS[workload]
+        self.triples = triples = load_graph(graph_name)
+        assert triples.shape[0] == E_g
+        # a second minibatch of the same size so that consecutive steps see different graphs (as in training, where
+        # t_func samples a new one every step): steps alternate A, B, A, B ...
+        if graph_name == "fb237_minibatch":
+            pool = load_graph("fb237_valid_test")
+            triples_b = np.ascontiguousarray(pool[np.random.RandomState(7).choice(pool.shape[0], size=E_g, replace=False)])
+        else:
+            triples_b = np.ascontiguousarray(triples[np.random.RandomState(7).permutation(E_g)])
+        self.params = init_encoder_params(V, R, d, L, kind, nb, rng=np.random.RandomState(1))
+        self.dcodes = (np.random.RandomState(2).randn(V, d) * 1e-3).astype(np.float32)
 
-    def allgather_scalar(x):
+        # RGCN_BENCH_SHARE_GPU=1 (tests only, with RGCN_RCCL_LIBRARY pointing at the shared-memory collective of
+        # tests/collective_double): every rank on device 0, to run the multi-process path on a one-GPU box.
+        # A launcher that masks the visible devices per rank leaves every rank with ONE device, index 0: take LOCAL_RANK only
+        # while the process sees that many devices (which GPU it is gets checked by PCI address in self_check).
+        n_visible, _ = _native.Engine.device_info(0)
+        self.device = 0 if os.environ.get("RGCN_BENCH_SHARE_GPU") == "1" or (world > 1 and n_visible == 1) else rk.local_rank
+        self.eng = eng = _native.Engine(V, R, d, L, kind, nb, keep_prob=0.8, norm_mode="intended", max_edges=E_g,
+                                        device=self.device, rank=rank, world=world)
+        if os.environ.get("RGCN_STREAMS", "1") == "0":      # bench.py's own switch (the PMC passes run on one stream)
+            eng.set_overlap(False)
+        eng.set_params(self.params)
+        if world > 1:
+            # One rank per GPU (launched by torch.distributed.run, which only provides the environment).
+            # The process keeps ONE ROCm stack: no torch import here; the 128-byte RCCL id travels through a
+            # file on this node (single-node contract), everything else (barriers, max over ranks) rides on
+            # the library's own RCCL communicator.
+            owner = lpt_partition(np.bincount(triples[:, 1], minlength=R), world)
+            eng.set_relation_owner(owner)
+            from relationprediction_amd.sharding import share_unique_id
+            uid = share_unique_id(rank, rk.rdv_path, _native.Engine.comm_unique_id)
+            eng.comm_init(uid)
+        self.rccl_ranks = eng.comm_info()[0] if world > 1 else None
+        self.comm_buf = eng.to_device(np.zeros(max(world, 1), dtype=np.float32)) if world > 1 else None
+        if world > 1:
+            self.self_check()
+        self.tri_dev = eng.to_device(triples)
+        self.tri_dev_b = eng.to_device(triples_b)
+        self.dc_dev = eng.to_device(self.dcodes)
+        self.graphs = [self.tri_dev, self.tri_dev_b]
+        self.pipeline = os.environ.get("RGCN_BENCH_PREFETCH", "1") != "0"
+        self.graph_id = None             # --hipgraph: the captured pair of steps
+        eng.set_gemm_mode(args.gemm_mode)
+
+    def allgather_scalar(self, x):
         """every rank's value, through a sum-all-reduce of a one-hot vector"""
-        v = np.zeros(world, dtype=np.float32)
-        v[rank] = x
-        comm_buf.upload(v)
-        eng.comm_allreduce_sum(comm_buf, world)
-        return comm_buf.download(np.float32, (world,))
-    if world > 1:
-        # First contact with a multi-GPU node must diagnose itself: the collective library has to SEE `world` ranks, and no two
-        # ranks may sit on one device (a mis-set LOCAL_RANK / HIP_VISIBLE_DEVICES gives N processes on GPU 0 that "scale"
-        # at 1/N).  What RCCL reports (ncclCommCount, ncclCommCuDevice) and the PCI address of that HIP device are gathered
-        # over the communicator itself; any mismatch ends the run with a non-zero exit instead of a number.
-        n_seen, r_seen, dev_seen = eng.comm_info()
-        pci = _native.Engine.device_info(dev_seen if dev_seen >= 0 else device)[1]
+        v = self.np.zeros(self.world, dtype=self.np.float32)
+        v[self.rank] = x
+        self.comm_buf.upload(v)
+        self.eng.comm_allreduce_sum(self.comm_buf, self.world)
+        return self.comm_buf.download(self.np.float32, (self.world,))
+
+    def self_check(self):
+        """First contact with a multi-GPU node must diagnose itself: the collective library has to SEE `world` ranks, and no
+        two ranks may sit on one device (a mis-set LOCAL_RANK / HIP_VISIBLE_DEVICES gives N processes on GPU 0 that "scale"
+        at 1/N).  What RCCL reports (ncclCommCount, ncclCommCuDevice) and the PCI address of that HIP device are gathered
+        over the communicator itself; any mismatch ends the run with a non-zero exit instead of a number."""
+        rank, world, device = self.rank, self.world, self.device
+        n_seen, r_seen, dev_seen = self.eng.comm_info()
+        pci = self.native.Engine.device_info(dev_seen if dev_seen >= 0 else device)[1]
         # (domain, bus << 8 | device) as two exact floats; an unknown address falls back to the device index
-        devs = list(zip(allgather_scalar(float(pci >> 16) if pci >= 0 else -1.0),
-                        allgather_scalar(float(pci & 0xffff) if pci >= 0 else float(device))))
-        ranks_seen = allgather_scalar(float(n_seen))
+        devs = list(zip(self.allgather_scalar(float(pci >> 16) if pci >= 0 else -1.0),
+                        self.allgather_scalar(float(pci & 0xffff) if pci >= 0 else float(device))))
+        ranks_seen = self.allgather_scalar(float(n_seen))
         problems = []
         if n_seen >= 0 and n_seen != world:      # (-1: the bound library has no ncclCommCount -- nothing to compare)
             problems.append("the collective library reports %d ranks, the launcher started %d" % (n_seen, world))
@@ -410,123 +426,102 @@ def measure(workload, args, rk, steps, warmup, full):
         if problems:
             sys.stderr.write("bench.py --gpus %d: multi-GPU self-check FAILED on rank %d: %s\n" % (world, rank, "; ".join(problems)))
             sys.exit(3)
-    tri_dev = eng.to_device(triples)
-    tri_dev_b = eng.to_device(triples_b)
-    dc_dev = eng.to_device(dcodes)
-    graphs = [tri_dev, tri_dev_b]
-    pipeline = os.environ.get("RGCN_BENCH_PREFETCH", "1") != "0"
 
-    def barrier():
-        eng.sync()
-        if world > 1:
-            allgather_scalar(1.0)      # returns only after every rank has joined the collective
-            eng.sync()
+    def barrier(self):
+        self.eng.sync()
+        if self.world > 1:
+            self.allgather_scalar(1.0)      # returns only after every rank has joined the collective
+            self.eng.sync()
 
-    def run(n, seed0, pipeline=pipeline):
-        # step i works on graph i % 2; while it runs, the next graph's CSR / message list is prepared
-        # on a side stream (what a training loop does with the next sampled minibatch)
+    def run(self, n, seed0, pipeline=None):
+        """n steps.  Step i works on graph i % 2; while it runs, the next graph's CSR / message list is prepared on a side
+        stream (what a training loop does with the next sampled minibatch).  After capture_two_steps: one launch of the
+        captured graph per two steps."""
+        pipeline = self.pipeline if pipeline is None else pipeline
+        if self.graph_id is not None and pipeline:
+            for _ in range(n // 2):
+                self.eng.graph_launch(self.graph_id)
+            return
         for i in range(n):
-            eng.step_device(graphs[i % 2], E_g, dc_dev, train=True, seed=seed0 + i)
+            self.eng.step_device(self.graphs[i % 2], self.E_g, self.dc_dev, train=True, seed=seed0 + i)
             if pipeline:
-                eng.prefetch_graph_device(graphs[(i + 1) % 2], E_g)
+                self.eng.prefetch_graph_device(self.graphs[(i + 1) % 2], self.E_g)
 
-    eng.set_gemm_mode(args.gemm_mode)
-    run(warmup, 1000)
-    use_graph = args.hipgraph and world == 1 and pipeline
-    if use_graph:
-        if steps % 2:
-            sys.exit("--hipgraph: --steps must be even (one launch = two steps)")
-        # steady state of the pipelined loop as ONE graph: step on A beside the preparation of B, then the reverse
-        # (RGCN_BENCH_GRAPH_NOPF=1, an A/B knob: no prefetches in the graph, every step prepares its own graph in line)
+    def capture_two_steps(self):
+        """--hipgraph: the steady state of the pipelined loop as ONE graph: step on A beside the preparation of B, then the
+        reverse (RGCN_BENCH_GRAPH_NOPF=1, an A/B knob: no prefetches in the graph, every step prepares its own graph in line)"""
+        eng, graphs, E_g = self.eng, self.graphs, self.E_g
         in_graph_prefetch = os.environ.get("RGCN_BENCH_GRAPH_NOPF") != "1"
         if in_graph_prefetch:
             eng.prefetch_graph_device(graphs[0], E_g)
         eng.sync()
         eng.capture_begin()
         for i in (0, 1):
-            eng.step_device(graphs[i], E_g, dc_dev, train=True, seed=2000 + i)
+            eng.step_device(graphs[i], E_g, self.dc_dev, train=True, seed=2000 + i)
             if in_graph_prefetch:
                 eng.prefetch_graph_device(graphs[1 - i], E_g)
-        graph_id = eng.capture_end()
-        plain_run = run
+        self.graph_id = eng.capture_end()
+        self.run(4, 0)
 
-        def run(n, seed0, pipeline=pipeline):   # noqa: F811  (timed loop: one launch per two steps)
-            if not pipeline:
-                return plain_run(n, seed0, pipeline=False)
-            for _ in range(n // 2):
-                eng.graph_launch(graph_id)
-        run(4, 0)
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    run(steps, 2000)
-    gpu_ms = eng.timer_stop()
-    eng.sync()
-    barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        wall = float(allgather_scalar(wall).max())     # max over ranks
-    ms_per_step = wall * 1e3 / steps
-    value = E_g * steps / wall
+    def timed(self, n, seed0, gpu_timer=False):
+        """n steps between barrier + device synchronisation on both sides: (wall seconds, max over ranks; HIP-event ms)"""
+        self.barrier()
+        t0 = time.perf_counter()
+        if gpu_timer:
+            self.eng.timer_start()
+        self.run(n, seed0)
+        gpu_ms = self.eng.timer_stop() if gpu_timer else None
+        self.eng.sync()
+        self.barrier()
+        wall = time.perf_counter() - t0
+        if self.world > 1:
+            wall = float(self.allgather_scalar(wall).max())
+        return wall, gpu_ms
 
-    # ---- the same loop once the device has settled (informative, never `value`): a fresh process's first ~30 steps run
-    # 6-13 % slower than the steady state (profiles/r05_first_steps_series.txt: every kernel alike, the device's power
-    # management after idle), and the driver's `--steps 20 --warmup 5` measures exactly those
-    steady = None
-    if full and world == 1:
+    def steady_state(self, steps_before):
+        """The same loop once the device has settled (informative, never `value`): a fresh process's first ~30 steps run
+        6-13 % slower than the steady state (profiles/r05_first_steps_series.txt: every kernel alike, the device's power
+        management after idle), and the driver's `--steps 20 --warmup 5` measures exactly those."""
         n_s = 40
-        run(15, 2500)
-        barrier()
-        t1 = time.perf_counter()
-        run(n_s, 2600)
-        eng.sync()
-        barrier()
-        wall_s = time.perf_counter() - t1
-        steady = {"ms_per_step": round(wall_s * 1e3 / n_s, 4), "value": round(E_g * n_s / wall_s, 1), "unit": "edges/s",
-                  "steps": n_s, "after_steps": warmup + steps + 15,
-                  "note": "the same loop continued after the timed region; informative only -- `value` is the timed region's"}
+        self.run(15, 2500)
+        wall_s, _ = self.timed(n_s, 2600)
+        return {"ms_per_step": round(wall_s * 1e3 / n_s, 4), "value": round(self.E_g * n_s / wall_s, 1), "unit": "edges/s",
+                "steps": n_s, "after_steps": steps_before + 15,
+                "note": "the same loop continued after the timed region; informative only -- `value` is the timed region's"}
 
-    # ---- the same step with the dense contractions on the fp32 MFMA (mode 0), for reference
-    fp32_ref = None
-    if full and args.gemm_mode != 0 and not args.no_fp32_reference:
+    def fp32_reference(self, steps):
+        """the same step with the dense contractions on the fp32 MFMA (mode 0), for reference"""
         n2 = max(10, steps // 2)
-        eng.set_gemm_mode(0)
-        run(3, 3000)
-        barrier()
-        t1 = time.perf_counter()
-        run(n2, 4000)
-        eng.sync()
-        barrier()
-        wall2 = time.perf_counter() - t1
-        if world > 1:
-            wall2 = float(allgather_scalar(wall2).max())
-        fp32_ref = {"value": round(E_g * n2 / wall2, 1), "unit": "edges/s", "ms_per_step": round(wall2 * 1e3 / n2, 4),
-                    "steps": n2, "arithmetic": "v_mfma_f32_32x32x2_f32 (rgcn_set_gemm_mode 0)"}
-        eng.set_gemm_mode(args.gemm_mode)
+        self.eng.set_gemm_mode(0)
+        self.run(3, 3000)
+        wall2, _ = self.timed(n2, 4000)
+        self.eng.set_gemm_mode(self.args.gemm_mode)
+        return {"value": round(self.E_g * n2 / wall2, 1), "unit": "edges/s", "ms_per_step": round(wall2 * 1e3 / n2, 4),
+                "steps": n2, "arithmetic": "v_mfma_f32_32x32x2_f32 (rgcn_set_gemm_mode 0)"}
 
-    # ---- per-kernel accounting: the same steps again with HIP events around every launch.
-    # Pass 1 as timed above (side streams + pipelined prep: durations of co-running kernels overlap and
-    # stretch); pass 2 with overlap off, every kernel alone on the main stream: EXCLUSIVE durations,
-    # which the per-kernel roofline numbers use.
-    kernels, roofline = [], None
-    if not args.no_kernel_profile:
+    def kernel_accounting(self, steps):
+        """Per-kernel accounting: the same steps again with HIP events around every launch.  Pass 1 as timed (side streams
+        + pipelined prep: durations of co-running kernels overlap and stretch); pass 2 with overlap off, every kernel alone
+        on the main stream: EXCLUSIVE durations, which the per-kernel roofline numbers use.  -> (kernels, roofline)"""
+        eng, args = self.eng, self.args
         eng.profile_reset()
         eng.profile_enable(True)
-        run(steps, 2000)
+        self.run(steps, 2000)
         in_pipeline = {p["name"]: p["total_ms"] / max(p["calls"], 1) for p in eng.profile()}
         eng.profile_enable(False)
         eng.set_overlap(False)
         eng.profile_reset()
         eng.profile_enable(True)
-        run(steps, 2000, pipeline=False)
+        self.run(steps, 2000, pipeline=False)
         prof = eng.profile()
         eng.profile_enable(False)
         eng.set_overlap(os.environ.get("RGCN_STREAMS", "1") != "0")
         kernels = kernel_table(prof, steps, args, in_pipeline)
-        traffic, traffic_src = traffic_table(workload)
+        traffic, traffic_src = traffic_table(self.workload)
         for k in kernels:
             k["traffic"] = kernel_traffic(traffic, k["kernel"], args)
         kernels.sort(key=lambda k: -k["ms_per_step"])
+        roofline = None
         if kernels:
             k = kernels[0]
             roofline = {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
@@ -540,11 +535,12 @@ def measure(workload, args, rk, steps, warmup, full):
             for extra in ("peak_is", "frac_of_fp32_mfma_peak", "frac_of_bf16_peak_on_alg_flops", "executed_bf16_tflops"):
                 if extra in k:
                     roofline[extra] = k[extra]
+        return kernels, roofline
 
-    # ---- the whole step against the chip (north_star: throughput "as achieved fraction of HBM roofline"):
-    # compulsory / design / PMC bytes and algorithmic flops of one step (this rank's share) over the measured step time
-    step_roofline = None
-    if kernels:
+    def step_roofline(self, kernels, ms_per_step):
+        """The whole step against the chip (north_star: throughput "as achieved fraction of HBM roofline"): compulsory /
+        design / PMC bytes and algorithmic flops of one step (this rank's share) over the measured step time."""
+        V, R, d, L, kind, nb, E_g = self.V, self.R, self.d, self.L, self.kind, self.nb, self.E_g
         P, I = 4.0 * V * d, 12.0 * E_g
         if kind == "block":
             sd = d // nb
@@ -559,34 +555,36 @@ def measure(workload, args, rk, steps, warmup, full):
         sf = sum(k["alg_flops"] * k["launches_per_step"] for k in kernels)
         sec = ms_per_step * 1e-3
         ceiling = compulsory / (PEAK_HBM_GBS * 1e9) + sf / (PEAK_F32_MFMA_TFS * 1e12)
-        step_roofline = {"compulsory_bytes_per_step": compulsory, "design_bytes_per_step": staged,
-                         "pmc_bytes_per_step": measured or None, "pmc_missing_kernels": missing,
-                         "alg_flops_per_step": sf,
-                         "hbm_gbs": round(compulsory / sec / 1e9, 1),
-                         "hbm_frac": round(compulsory / sec / 1e9 / PEAK_HBM_GBS, 4),
-                         "hbm_frac_design": round(staged / sec / 1e9 / PEAK_HBM_GBS, 4),
-                         "fp32_tflops": round(sf / sec / 1e12, 2),
-                         "fp32_mfma_frac": round(sf / sec / 1e12 / PEAK_F32_MFMA_TFS, 4),
-                         "serial_ceiling_ms": round(ceiling * 1e3, 4),
-                         "frac_of_serial_ceiling": round(ceiling / sec, 4),
-                         "sum_exclusive_kernel_ms": round(sum(k["ms_per_step"] for k in kernels), 4),
-                         "note": "whole step on this rank over the measured step time.  compulsory = SURVEY 8d's "
-                                 "L*(2I+5P+3W)+4P (each distinct input read once, each output written once); "
-                                 "design = what the kernels move by construction (messages staged through "
-                                 "HBM / L2 between the relation-major and the row-major stage); pmc = rocprofv3 "
-                                 "FETCH/WRITE_SIZE bytes of the committed PMC passes x launches; ceiling = "
-                                 "compulsory / 8 TB/s + fp32 flops / 157.3 TF with nothing overlapped"}
+        return {"compulsory_bytes_per_step": compulsory, "design_bytes_per_step": staged,
+                "pmc_bytes_per_step": measured or None, "pmc_missing_kernels": missing,
+                "alg_flops_per_step": sf,
+                "hbm_gbs": round(compulsory / sec / 1e9, 1),
+                "hbm_frac": round(compulsory / sec / 1e9 / PEAK_HBM_GBS, 4),
+                "hbm_frac_design": round(staged / sec / 1e9 / PEAK_HBM_GBS, 4),
+                "fp32_tflops": round(sf / sec / 1e12, 2),
+                "fp32_mfma_frac": round(sf / sec / 1e12 / PEAK_F32_MFMA_TFS, 4),
+                "serial_ceiling_ms": round(ceiling * 1e3, 4),
+                "frac_of_serial_ceiling": round(ceiling / sec, 4),
+                "sum_exclusive_kernel_ms": round(sum(k["ms_per_step"] for k in kernels), 4),
+                "note": "whole step on this rank over the measured step time.  compulsory = SURVEY 8d's "
+                        "L*(2I+5P+3W)+4P (each distinct input read once, each output written once); "
+                        "design = what the kernels move by construction (messages staged through "
+                        "HBM / L2 between the relation-major and the row-major stage); pmc = rocprofv3 "
+                        "FETCH/WRITE_SIZE bytes of the committed PMC passes x launches; ceiling = "
+                        "compulsory / 8 TB/s + fp32 flops / 157.3 TF with nothing overlapped"}
 
-    # ---- CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1
-    cpu = None
-    if full and rank == 0 and world == 1 and args.cpu_steps > 0:
+    def cpu_baseline(self):
+        """CPU baseline: the oracle (port of the reference's TF dataflow) on this host, rank 0, N=1"""
         import oracle  # test infrastructure; used here ONLY as the timed CPU baseline
+        np, V, d, L, kind, E_g = self.np, self.V, self.d, self.L, self.kind, self.E_g
         masks = [(np.random.RandomState(3 + l).rand(V, d) < 0.8).astype(np.uint8) for l in range(L)]
-        oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)  # warm-up
+        step = lambda: oracle.encoder_step(self.params, self.triples, V, L, kind, self.dcodes, keep_prob=0.8,  # noqa: E731
+                                           dropout_masks=masks)
+        step()  # warm-up
         ts = []
-        for _ in range(args.cpu_steps):
+        for _ in range(self.args.cpu_steps):
             c0 = time.perf_counter()
-            oracle.encoder_step(params, triples, V, L, kind, dcodes, keep_prob=0.8, dropout_masks=masks)
+            step()
             ts.append(time.perf_counter() - c0)
         med = float(np.median(ts))
         model_name = ""
@@ -595,16 +593,17 @@ def measure(workload, args, rk, steps, warmup, full):
                 model_name = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
         except OSError:
             pass
-        cpu = {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "cpu_model": model_name,
-               "kind": "port",
-               "ms_per_step": round(med * 1e3, 1),
-               "threads": "BLAS threads = host cores for the dense products (self-loop, basis); the sparse incidence "
-                          "products, gathers and batched 5x5 products of the TF-shaped dataflow run on one thread",
-               "sample": "%d steps of the same %s minibatch (E_g=%d) through oracle.encoder_step "
-                         "(numpy/scipy fp32, TF-dataflow-shaped), median" % (args.cpu_steps, workload, E_g)}
+        return {"value": round(E_g / med, 1), "unit": "edges/s", "cores": os.cpu_count(), "cpu_model": model_name,
+                "kind": "port",
+                "ms_per_step": round(med * 1e3, 1),
+                "threads": "BLAS threads = host cores for the dense products (self-loop, basis); the sparse incidence "
+                           "products, gathers and batched 5x5 products of the TF-shaped dataflow run on one thread",
+                "sample": "%d steps of the same %s minibatch (E_g=%d) through oracle.encoder_step "
+                          "(numpy/scipy fp32, TF-dataflow-shaped), median" % (self.args.cpu_steps, self.workload, E_g)}
 
-    out = None
-    if rank == 0:
+    def describe_data(self):
+        """-> (dataset name, the `data` sentence, config.graph)"""
+        workload, graph_name, E_g = self.workload, self.graph_name, self.E_g
         dataset = {"wn18": "WN18", "toy_": "Toy", "fb15": "FB15k"}.get(workload[:4], "FB15k-237")
         graph_spec = None
         if graph_name.startswith("synth:"):
@@ -623,8 +622,44 @@ def measure(workload, args, rk, steps, warmup, full):
                     % (E_g, n_graph, dataset, pool))
         else:
             data = "real graph structure (fixture %s of tests/golden/graphs.npz, %d edges; SURVEY 8d), " % (graph_name, E_g)
+        return dataset, data, graph_spec or {"kind": "fixture", "name": graph_name}
+
+    def close(self):
+        self.tri_dev.free()
+        self.tri_dev_b.free()
+        self.dc_dev.free()
+        if self.comm_buf is not None:
+            self.comm_buf.free()
+        self.eng.close()
+
+
+def measure(workload, args, rk, steps, warmup, full):
+    """One workload on this rank's engine: W untimed steps, then EXACTLY `steps` timed ones (barrier + sync on both sides,
+    max over ranks) -- `value` comes from that region and nothing else --, then the informative legs and the per-kernel
+    passes.  full = the headline extras (steady state, fp32-MFMA reference run, CPU baseline)."""
+    b = EncoderBench(workload, args, rk)
+    rank, world = b.rank, b.world
+    b.run(warmup, 1000)
+    use_graph = args.hipgraph and world == 1 and b.pipeline
+    if use_graph:
+        if steps % 2:
+            sys.exit("--hipgraph: --steps must be even (one launch = two steps)")
+        b.capture_two_steps()
+    wall, gpu_ms = b.timed(steps, 2000, gpu_timer=True)
+    ms_per_step = wall * 1e3 / steps
+    value = b.E_g * steps / wall
+
+    steady = b.steady_state(warmup + steps) if full and world == 1 else None
+    fp32_ref = b.fp32_reference(steps) if full and args.gemm_mode != 0 and not args.no_fp32_reference else None
+    kernels, roofline = ([], None) if args.no_kernel_profile else b.kernel_accounting(steps)
+    step_roofline = b.step_roofline(kernels, ms_per_step) if kernels else None
+    cpu = b.cpu_baseline() if full and rank == 0 and world == 1 and args.cpu_steps > 0 else None
+
+    out = None
+    if rank == 0:
+        dataset, data, graph_spec = b.describe_data()
         out = {
-            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % (dataset, kind),
+            "metric": "processed edges/sec (R-GCN forward+backward), %s gcn_%s" % (dataset, b.kind),
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
@@ -632,14 +667,14 @@ def measure(workload, args, rk, steps, warmup, full):
                      "f32 (dense contractions: fp32 operands split exactly into 3 bf16, %d of 9 partial products on the "
                      "bf16 matrix cores, fp32 accumulation; error vs float64 equal to the fp32 MFMA's)" % args.gemm_mode,
             "data": data + "reference-distribution random-init weights, synthetic upstream gradient",
-            "config": {"workload": workload, "graph": graph_spec or {"kind": "fixture", "name": graph_name},
-                       "entities": V, "relations": R, "dim": d, "layers": L,
-                       "kind": kind, "num_blocks_or_bases": nb, "graph_edges": E_g,
+            "config": {"workload": workload, "graph": graph_spec,
+                       "entities": b.V, "relations": b.R, "dim": b.d, "layers": b.L,
+                       "kind": b.kind, "num_blocks_or_bases": b.nb, "graph_edges": b.E_g,
                        "norm_mode": "intended (1/deg of the edge's own row; SURVEY H1, DESIGN section 10)",
                        "step": ("device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads); "
                                 "two alternating minibatches, next graph's prep pipelined on a side stream"
                                 + ("; replayed from a captured hipGraph (2 steps per launch)" if use_graph else ""))
-                               if pipeline else
+                               if b.pipeline else
                                "device graph prep + encoder fwd (train, dropout) + bwd (all encoder grads)",
                        "parallelism": "relation-sharded x%d + RCCL reduce-scatter / all-gather per layer, one all-reduce "
                                       "of the replicated weight gradients" % world if world > 1 else "single GPU"},
@@ -647,22 +682,17 @@ def measure(workload, args, rk, steps, warmup, full):
             # collectives of one step on this rank (exclusive durations of the rccl_* launches; N = 1: none)
             "comm_ms_per_step": round(sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("rccl_")), 4),
             # what the collective library itself says about the communicator (ncclCommCount): N ranks seen, or -1
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": b.rccl_ranks,
             "collectives": [[k["kernel"], k["launches_per_step"], k["avg_us"]] for k in kernels
                             if k["kernel"].startswith("rccl_")],
-            "message_edges_per_s": round(2 * L * value, 1),
+            "message_edges_per_s": round(2 * b.L * value, 1),
             "roofline": roofline, "step_roofline": step_roofline, "kernels": kernels, "cpu_baseline": cpu,
             "fp32_mfma_reference": fp32_ref,
             "steady_state": steady,
         }
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
-    tri_dev.free()
-    tri_dev_b.free()
-    dc_dev.free()
-    if comm_buf is not None:
-        comm_buf.free()
-    eng.close()
+    b.close()
     return out
 
 
