@@ -104,6 +104,25 @@ def test_no_gpu_means_loud_failure(lib_path):
         _native.Engine(16, 9, 10, 1, "block", 2, max_edges=50)
 
 
+def test_device_info_is_context_free_and_reports_no_device_without_a_gpu(lib_path):
+    """rgcn_device_info needs no context (bench.py --gpus N calls it before it creates one): without a GPU it reports zero
+    devices and no PCI address, and NULL outputs are refused."""
+    lib = ctypes.CDLL(lib_path)
+    lib.rgcn_device_info.restype = ctypes.c_int32
+    lib.rgcn_device_info.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    n, pci = ctypes.c_int32(-7), ctypes.c_int64(-7)
+    assert lib.rgcn_device_info(0, None, ctypes.byref(pci)) == 1          # RGCN_ERR_INVALID
+    assert lib.rgcn_device_info(0, ctypes.byref(n), ctypes.byref(pci)) == 0
+    if os.path.exists("/dev/kfd"):
+        assert n.value >= 1 and pci.value >= 0
+        assert lib.rgcn_device_info(n.value, ctypes.byref(n), ctypes.byref(pci)) == 0 and pci.value == -1   # past the last one
+    else:
+        assert (n.value, pci.value) == (0, -1)
+    from relationprediction_amd import _native
+    count, address = _native.Engine.device_info(0)                           # the ctypes binding of the same call
+    assert lib.rgcn_device_info(0, ctypes.byref(n), ctypes.byref(pci)) == 0 and (count, address) == (n.value, pci.value)
+
+
 def test_library_has_no_packed_fp32_instructions():
     """gfx950: packed-FP32 VALU ops return wrong low halves beside waves that issue bf16 MFMAs
     (tools/mfma_corun.hip); the build switches the feature off and this checks the linked code objects."""
